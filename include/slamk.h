@@ -1,0 +1,157 @@
+/*
+ * slamk.h -- C ABI of the MI355X EKF predict/update library (libslamk.so).
+ *
+ * The reference estimator (presocratics/slam, src/slam) has no FFI layer: its hot path
+ * is a set of C++ free functions and class methods called once per sensor time step from
+ * main()'s while loop (src/slam/main.cpp:150-236).  This header is the boundary a
+ * maintainer binds instead; every entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - fp64 everywhere; quaternions are scalar-last (src/ARC/Quaternion.cpp:32-47).
+ *   - A handle owns `batch` independent filters of at most `max_features` features each.
+ *     State vector order per filter: X(3) V(3) feature_0(3) .. feature_{nf-1}(3) bias(3),
+ *     n = 9 + 3 nf (src/ARC/states.cpp:24-37,267-270).
+ *   - Measurement vector order per filter: altitude, then per feature slot
+ *     current(2) initial(2) [reflection(2) if the feature was initialised with one],
+ *     m = 1 + 6 rf + 4 nrf (src/ARC/view.cpp:3-26, src/slam/main.cpp:353).
+ *   - Pointers are caller-owned HOST memory unless the name ends in _dev.
+ *   - Every function returns 0 or a negative SLAMK_E* code and never exits the process;
+ *     slamk_last_error() gives the text.  A handle may be used from one thread at a time.
+ */
+#ifndef SLAMK_H
+#define SLAMK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct slamk_handle slamk_handle;
+
+enum {
+    SLAMK_OK = 0,
+    SLAMK_EINVAL = -1,      /* bad argument / size */
+    SLAMK_EHIP = -2,        /* HIP runtime error */
+    SLAMK_ENOMATCH = -3,    /* "Cannot find match."            src/slam/main.cpp:372-375 */
+    SLAMK_EREFL = -4,       /* reflection rows of H, R, e disagree: the reference aborts in
+                               cv::Mat arithmetic here (src/slam/main.cpp:211-218,353; src/ARC/view.cpp:17,39) */
+    SLAMK_ECAPACITY = -5    /* more features than max_features */
+};
+
+/* Compile-time constants of the reference, as run-time parameters with the same defaults:
+ * Q0,R0 src/slam/main.cpp:115-116; qbias src/slam/main.h:25; p0 src/ARC/states.cpp:136,164;
+ * pinit src/slam/main.cpp:44; alt_override :177; gate :232; d_min,d_max src/ARC/states.cpp:91-92;
+ * dinit src/ARC/feature.cpp:20. */
+typedef struct {
+    double Q0, R0, qbias, p0, pinit;
+    double alt_override;
+    int32_t use_alt_override;
+    double gate, d_min, d_max, dinit;
+    /* 0: gain by Cholesky of S, covariance by the Joseph form (I-KH)P(I-KH)^T + K R K^T.
+     * 1: gain by Cholesky of S, covariance as the reference writes it, (I-KH)P then (P+P^T)/2
+     *    (src/slam/main.cpp:561-569).  Both equal the reference's LU form up to rounding. */
+    int32_t update_form;
+} slamk_params;
+
+/* One image-feature observation, include/featureIO.h:31-37 (`projection`). */
+typedef struct {
+    int32_t id;
+    double sx, sy;     /* source */
+    double rx, ry;     /* reflection; (0,0) = none */
+} slamk_match;
+
+void slamk_default_params(slamk_params* p);
+
+/* Allocates device state and workspaces for `batch` filters on HIP device `device`.
+ * Every filter starts like main() does: X=V=bias=0, no features,
+ * P = diag(pinit x3, 1 x3, pinit x3)  (src/slam/main.cpp:121-123,130). */
+int slamk_create(const slamk_params* p, int max_features, int batch, int device, slamk_handle** out);
+int slamk_destroy(slamk_handle* h);
+const char* slamk_last_error(const slamk_handle* h);
+
+/* ---- state access (replaces direct member access to States / Feature / cv::Mat P) ---- */
+/* Any of X, V, bias may be NULL = leave unchanged.  b = filter index. */
+int slamk_set_state(slamk_handle* h, int b, const double* X, const double* V, const double* bias);
+int slamk_get_state(slamk_handle* h, int b, double* X, double* V, double* bias);
+/* P is n x n row-major with leading dimension ld, n must equal 9 + 3 nf of filter b. */
+int slamk_set_cov(slamk_handle* h, int b, const double* P, int n, int ld);
+int slamk_get_cov(slamk_handle* h, int b, double* P, int n, int ld);
+/* Feature containers as AoS arrays of nf entries: id[nf], pib[3nf], anchor[3nf], q0[4nf],
+ * pib0[2nf], is_ref[nf]  (include/feature.h:15-25,217-220).  Resizes the filter to nf features;
+ * the covariance is NOT touched (follow with slamk_set_cov). */
+int slamk_set_features(slamk_handle* h, int b, int nf, const int32_t* id, const double* pib,
+                       const double* anchor, const double* q0, const double* pib0, const uint8_t* is_ref);
+/* Any output pointer may be NULL.  *nf receives the feature count. */
+int slamk_get_features(slamk_handle* h, int b, int* nf, int32_t* id, double* pib, double* anchor,
+                       double* q0, double* pib0, uint8_t* is_ref);
+int slamk_num_features(slamk_handle* h, int b);
+/* Measurement dimension m of filter b for its current feature set. */
+int slamk_num_rows(slamk_handle* h, int b);
+
+/* ---- image frame: the `if (u & UPDATE_IMG)` branch, src/slam/main.cpp:167-175 -------- */
+/* old_pos = X; inverse depths clamped to [1/d_max, 1/d_min]; association of `matches` with the
+ * tracked ids: new ids take the first unmatched slot, else are appended; unmatched features are
+ * erased; P rows/cols are inserted / reset / deleted to follow (States::update_features,
+ * src/ARC/states.cpp:88-213; Feature::initialize, src/ARC/feature.cpp:48-91).  Slot order and
+ * ids are bit-exact with the reference.  The frame's observations are kept, in slot order, as the
+ * measurement of the next slamk_update for this filter.  b = -1 applies the same frame to every
+ * filter of the batch (they must hold the same ids). */
+int slamk_frame(slamk_handle* h, int b, const slamk_match* matches, int nmatch, const double quat[4]);
+/* Replaces only the observation values (not ids / reflection presence) of the frame kept for
+ * filter b: src2/refl2 are [nf][2] in slot order.  For Monte-Carlo batches that share one
+ * association but carry independent pixel noise. */
+int slamk_set_frame_values(slamk_handle* h, int b, const double* src2, const double* refl2);
+
+/* ---- predict: src/slam/main.cpp:192-194,204-206 --------------------------------------- */
+/* F = jacobianMotionModel(mu) at the pre-predict state (:241-341); mu += dynamics(mu) dt
+ * (States::dynamics, src/ARC/states.cpp:222-263); Q = initQ (:430-440); P = F P F^T + Q
+ * (calcP, :526-530, with G = I).  Per filter b: qbw[4b..], w[3b..], acc[3b..], dt[b]. */
+int slamk_predict(slamk_handle* h, const double* qbw, const double* w, const double* acc, const double* dt);
+
+/* ---- update: src/slam/main.cpp:198-202,209-233 ------------------------------------------ */
+/* measurementModel + jacobianH (:348-408,:575-624; Feature::pib0Hat/ppbHat,
+ * src/ARC/feature.cpp:143-198) at the post-predict state, with pib0Hat at old_pos;
+ * R = initR (:449-476); S = H P H^T + R; K = P H^T S^-1 (calcK, :539-552);
+ * covariance update (updateP, :561-569; see slamk_params.update_form);
+ * dx = K (meas - hmu) (View subtract/toMat, src/ARC/view.cpp:3-47); gated mean update
+ * `if (sum|V - dV| < gate) mu += dx` (:228-232, States(const Mat&), src/ARC/states.cpp:24-37).
+ * qbw[4b..]; alt[b] is ignored when use_alt_override (:177).  The observations are the ones
+ * kept by slamk_frame.  applied[b] (may be NULL) = 1 if the mean update passed the gate, else 0. */
+int slamk_update(slamk_handle* h, const double* qbw, const double* alt, int* applied);
+
+/* ---- device-pointer variants: inputs already in HBM, launched on `stream` (a hipStream_t),
+ * no host synchronisation.  Layouts: qbw_dev [B][4], w_dev/acc_dev [B][3], dt_dev/alt_dev [B],
+ * src_dev/refl_dev [B][2][max_features] (component-major per filter, slot order),
+ * applied_dev int32 [B] (may be NULL).  src_dev/refl_dev NULL = use the kept frame. */
+int slamk_frame_begin_dev(slamk_handle* h, void* stream);   /* old_pos = X and depth clamp, all filters */
+int slamk_predict_dev(slamk_handle* h, const double* qbw_dev, const double* w_dev, const double* acc_dev,
+                      const double* dt_dev, void* stream);
+int slamk_update_dev(slamk_handle* h, const double* qbw_dev, const double* alt_dev, const double* src_dev,
+                     const double* refl_dev, int32_t* applied_dev, void* stream);
+/* Waits for `stream` and returns SLAMK_EREFL / SLAMK_OK from the per-filter status words. */
+int slamk_sync(slamk_handle* h, void* stream);
+
+/* ---- introspection for tests and benchmarks (no counterpart in the reference) ----------- */
+/* Copies of the last update's intermediates of filter b (NULL = skip): H m x n, S's Cholesky
+ * factor L m x m (lower), K n x m, innovation e[m]. */
+int slamk_debug_get(slamk_handle* h, int b, double* H, double* L, double* K, double* e);
+/* Dense motion Jacobian of the last predict, n x n. */
+int slamk_debug_get_F(slamk_handle* h, int b, double* F);
+/* Plain strided-batched DGEMM on device pointers through the library's MFMA kernel:
+ * C = alpha A op(B) + beta C; all of M, N, K multiples of 16; trans_b != 0 means B is N x K. */
+int slamk_dgemm_dev(int trans_b, int M, int N, int K, double alpha, const double* A_dev, int lda,
+                    long long strideA, const double* B_dev, int ldb, long long strideB, double beta,
+                    double* C_dev, int ldc, long long strideC, int batch, void* stream);
+/* Issue-rate probe: runs `iters` dependent-free v_mfma_f64_16x16x4_f64 per wave on every CU and
+ * returns the achieved TFLOP/s in *tflops. */
+int slamk_mfma_f64_probe(int iters, double* tflops);
+/* FLOPs the covariance kernels execute for one predict / one update of a filter with the given
+ * padded dimensions (what roofline fractions are computed from). */
+double slamk_flops_predict(int n);
+double slamk_flops_update(int n, int m, int update_form);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAMK_H */

@@ -1,0 +1,195 @@
+// fp64 MFMA GEMM for gfx950 (v_mfma_f64_16x16x4_f64), row-major, strided-batched.
+//
+//   C = alpha * A * op(B) + beta * C        A: M x K (lda),  C: M x N (ldc)
+//   op(B) = B^T with B: N x K (ldb)  when TB,   op(B) = B with B: K x N (ldb) otherwise.
+//
+// One 256-thread workgroup (4 waves as 2 x 2) owns a BM x BN tile of C; each wave owns a
+// (BM/2) x (BN/2) sub-tile as TM x TN accumulators of 16 x 16.  K is walked in slabs of 16:
+// the next slab is fetched from global memory into registers while the MFMAs of the current
+// slab run out of LDS (register-staged software pipeline, one LDS buffer).
+//
+// LDS images are laid out so that the 64-bit operand reads are bank-conflict free:
+//   k-contiguous operands (A, and B when TB) : [row][18]  -> lane (i = l&15, kk = l>>4) reads
+//       dword 36 i + 2 kk (+8 s): the 32 lanes of a half-wave hit 32 distinct even banks.
+//   n-contiguous operand (B when !TB)        : [k][BN+16] -> row stride 2(BN+16) dwords == 32 mod 64,
+//       so the two k rows a half-wave touches land in opposite halves of the 64 banks.
+//
+// All of M, N, K must be multiples of 16 (the filter keeps its matrices zero-padded to 16);
+// tile edges are handled by zero-filling loads and guarding stores at that granularity.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace slamk {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+enum Epilogue {
+    EPI_NONE = 0,
+    EPI_DIAG_ADD = 1,    // C[i][i] += D[i]              (P = F T + Q,  S = H W + R)
+    EPI_EYE_MINUS = 2,   // C = I - A*op(B)              (A = I - K H)
+    EPI_DUAL_COLSCALE = 3  // C = acc and C2[i][j] = acc * D[j]   (K and K R with diagonal R in one pass)
+};
+
+// Which k range can be skipped because one operand is block lower-triangular.
+enum TriMode {
+    TRI_NONE = 0,
+    TRI_B_KLE_N = 1,     // op(B)[k][n] == 0 for k >= n0 + BN   (B^T with B lower)
+    TRI_B_KGE_N = 2,     // op(B)[k][n] == 0 for k <  n0        (B lower, not transposed)
+    TRI_A_KLE_M = 3      // A[m][k]     == 0 for k >= m0 + BM   (A lower)
+};
+
+struct GemmArgs {
+    const double* A;
+    const double* B;
+    double* C;
+    double* C2;           // second output of EPI_DUAL_COLSCALE (same ld and strides as C)
+    const double* D;      // diagonal / column-scale vector for the epilogue (may be null)
+    int M, N, K;
+    int lda, ldb, ldc;
+    long long sA1, sB1, sC1, sD1;   // batch level 1 (independent filters)
+    long long sA2, sB2, sC2;        // batch level 2 (sub-blocks inside one matrix)
+    int nb2;                        // level-2 count (>= 1); blockIdx.z = b1 * nb2 + b2
+    double alpha, beta;
+};
+
+template <int BM, int BN, bool TB, int EPI, bool LOWER, int TRI>
+__global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmArgs g)
+{
+    constexpr int LDS_K = 18;                       // row stride of k-contiguous images (doubles)
+    constexpr int LDS_N = BN + 16;                  // row stride of the n-contiguous B image
+    constexpr int TM = BM / 32, TN = BN / 32;
+    __shared__ double As[BM * LDS_K];
+    __shared__ double Bs[TB ? BN * LDS_K : 16 * LDS_N];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if (LOWER && n0 > m0 + BM - 1) return;          // tile lies strictly above the diagonal
+
+    const int b1 = blockIdx.z / g.nb2, b2 = blockIdx.z - b1 * g.nb2;
+    const double* __restrict__ A = g.A + b1 * g.sA1 + b2 * g.sA2;
+    const double* __restrict__ B = g.B + b1 * g.sB1 + b2 * g.sB2;
+    double* __restrict__ C = g.C + b1 * g.sC1 + b2 * g.sC2;
+    double* __restrict__ C2 = (EPI == EPI_DUAL_COLSCALE) ? g.C2 + b1 * g.sC1 + b2 * g.sC2 : nullptr;
+    const double* __restrict__ D = g.D ? g.D + b1 * g.sD1 : nullptr;
+
+    int kb = 0, ke = g.K;
+    if (TRI == TRI_B_KLE_N) ke = min(g.K, n0 + BN);
+    if (TRI == TRI_B_KGE_N) kb = min(g.K, n0);
+    if (TRI == TRI_A_KLE_M) ke = min(g.K, m0 + BM);
+
+    v4d acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    double2 ra[TM], rb[TN];
+    const int arow = tid >> 3, akp = (tid & 7) * 2;                 // k-contiguous staging map
+    constexpr int BLPR = BN / 2;                                    // lanes per row of the n-contiguous image
+    const int brow = tid / BLPR, bcol = (tid % BLPR) * 2;
+
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int r = 0; r < TM; ++r) {
+            const int gr = m0 + arow + 32 * r;
+            ra[r] = (gr < g.M) ? *reinterpret_cast<const double2*>(A + (long long)gr * g.lda + k0 + akp)
+                               : make_double2(0.0, 0.0);
+        }
+        if (TB) {
+#pragma unroll
+            for (int r = 0; r < TN; ++r) {
+                const int gr = n0 + arow + 32 * r;
+                rb[r] = (gr < g.N) ? *reinterpret_cast<const double2*>(B + (long long)gr * g.ldb + k0 + akp)
+                                   : make_double2(0.0, 0.0);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < TN; ++r) {
+                const int k = brow + (256 / BLPR) * r;
+                const int gc = n0 + bcol;
+                rb[r] = (gc < g.N) ? *reinterpret_cast<const double2*>(B + (long long)(k0 + k) * g.ldb + gc)
+                                   : make_double2(0.0, 0.0);
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int r = 0; r < TM; ++r)
+            *reinterpret_cast<double2*>(&As[(arow + 32 * r) * LDS_K + akp]) = ra[r];
+        if (TB) {
+#pragma unroll
+            for (int r = 0; r < TN; ++r)
+                *reinterpret_cast<double2*>(&Bs[(arow + 32 * r) * LDS_K + akp]) = rb[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < TN; ++r)
+                *reinterpret_cast<double2*>(&Bs[(brow + (256 / BLPR) * r) * LDS_N + bcol]) = rb[r];
+        }
+    };
+
+    const int li = lane & 15, lk = lane >> 4;
+    const double* aBase = &As[(wr * (BM / 2) + li) * LDS_K + lk];
+    const double* bBase = TB ? &Bs[(wc * (BN / 2) + li) * LDS_K + lk] : &Bs[lk * LDS_N + wc * (BN / 2) + li];
+
+    if (kb < ke) fetch(kb);
+    for (int k0 = kb; k0 < ke; k0 += 16) {
+        __syncthreads();                 // every wave is done reading the previous slab
+        stash();
+        __syncthreads();
+        if (k0 + 16 < ke) fetch(k0 + 16);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            double a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = aBase[i * 16 * LDS_K + 4 * s];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = TB ? bBase[j * 16 * LDS_K + 4 * s] : bBase[4 * s * LDS_N + j * 16];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // accumulator layout of v_mfma_f64_16x16x4_f64: lane l, register r -> row (l>>4) + 4 r, col l & 15
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wc * (BN / 2) + j * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wr * (BM / 2) + i * 16 + lk + 4 * r;
+                if (row < g.M && col < g.N) {
+                    double v = g.alpha * acc[i][j][r];
+                    double* c = C + (long long)row * g.ldc + col;
+                    if (EPI == EPI_EYE_MINUS) v = (row == col ? 1.0 : 0.0) - v;
+                    if (g.beta != 0.0) v += g.beta * (*c);
+                    if (EPI == EPI_DIAG_ADD && row == col) v += D[row];
+                    *c = v;
+                    if (EPI == EPI_DUAL_COLSCALE) C2[(long long)row * g.ldc + col] = v * D[col];
+                }
+            }
+        }
+    }
+}
+
+// Host-side launcher.  Picks 128x128 tiles for large problems and 64x64 for small ones.
+template <bool TB, int EPI, bool LOWER, int TRI>
+inline hipError_t launch_gemm(const GemmArgs& g, int batch, hipStream_t stream)
+{
+    if (g.M <= 0 || g.N <= 0 || batch <= 0) return hipSuccess;
+    const bool big = (g.M >= 512 && g.N >= 512);
+    if (big) {
+        dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, batch);
+        hipLaunchKernelGGL((gemm_f64_kernel<128, 128, TB, EPI, LOWER, TRI>), grid, dim3(256), 0, stream, g);
+    } else {
+        dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, batch);
+        hipLaunchKernelGGL((gemm_f64_kernel<64, 64, TB, EPI, LOWER, TRI>), grid, dim3(256), 0, stream, g);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace slamk

@@ -1,0 +1,793 @@
+// libslamk.so -- C ABI (include/slamk.h) over the HIP kernels of the EKF predict/update path.
+// gfx950 only.
+#include "../../include/slamk.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "feature_kernels.hip.h"
+#include "gemm.hip.h"
+#include "linalg_kernels.hip.h"
+
+using namespace slamk;
+
+namespace {
+
+inline int pad16(int x) { return (x + 15) / 16 * 16; }
+
+struct HostFilter {            // host mirror of what association needs (ids are never on the hot path)
+    int nf = 0;
+    std::vector<int32_t> id;
+    std::vector<uint8_t> isref;
+    int m() const {
+        int r = 1;
+        for (int i = 0; i < nf; ++i) r += isref[i] ? 6 : 4;
+        return r;
+    }
+};
+
+}  // namespace
+
+struct slamk_handle {
+    slamk_params prm;
+    int B = 0, F = 0, device = 0;
+    int ldn = 0, ldm = 0;
+    std::vector<HostFilter> hf;
+    FilterView fv{};
+    // dense workspaces
+    double *Fm = nullptr, *T = nullptr, *Am = nullptr, *AP = nullptr;          // [B][ldn][ldn]
+    double *Hm = nullptr;                                                        // [B][ldm][ldn]
+    double *W = nullptr, *Y = nullptr, *K = nullptr, *KR = nullptr;              // [B][ldn][ldm]
+    double *S = nullptr, *L = nullptr, *Li = nullptr;                            // [B][ldm][ldm]
+    double *dx = nullptr;                                                        // [B][ldn]
+    // staging
+    double *qbw_d = nullptr, *w_d = nullptr, *acc_d = nullptr, *dt_d = nullptr, *alt_d = nullptr;
+    int *applied_d = nullptr;
+    int *map_d = nullptr;                 // [ldn] index map for surgery
+    double *feat_tmp = nullptr;           // [4][F] scratch for slot gathers
+    std::vector<void*> allocs;
+    std::string err;
+    hipStream_t stream = nullptr;
+    int last_nl = 0, last_ml = 0;
+};
+
+namespace {
+
+int fail(slamk_handle* h, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) return fail(h, SLAMK_EHIP, "%s: %s", #call, hipGetErrorString(e_));  \
+    } while (0)
+
+template <typename T>
+int dalloc(slamk_handle* h, T** p, size_t count)
+{
+    void* q = nullptr;
+    HIPCHK(h, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+    HIPCHK(h, hipMemset(q, 0, std::max<size_t>(count, 1) * sizeof(T)));
+    h->allocs.push_back(q);
+    *p = static_cast<T*>(q);
+    return 0;
+}
+
+int max_nl(const slamk_handle* h)
+{
+    int nf = 0;
+    for (const auto& f : h->hf) nf = std::max(nf, f.nf);
+    return pad16(9 + 3 * nf);
+}
+int max_ml(const slamk_handle* h)
+{
+    int m = 1;
+    for (const auto& f : h->hf) m = std::max(m, f.m());
+    return pad16(m);
+}
+
+GemmArgs gargs(const double* A, int lda, long long sA, const double* Bp, int ldb, long long sB, double* C, int ldc,
+               long long sC, int M, int N, int K, double alpha = 1.0, double beta = 0.0, const double* D = nullptr,
+               long long sD = 0)
+{
+    GemmArgs g{};
+    g.A = A; g.B = Bp; g.C = C; g.C2 = nullptr; g.D = D;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.sA1 = sA; g.sB1 = sB; g.sC1 = sC; g.sD1 = sD;
+    g.sA2 = g.sB2 = g.sC2 = 0;
+    g.nb2 = 1;
+    g.alpha = alpha; g.beta = beta;
+    return g;
+}
+
+// Uploads nf/m/isref/rowoff of filter b from the host mirror.
+int push_layout(slamk_handle* h, int b)
+{
+    const HostFilter& f = h->hf[b];
+    const int F = h->F;
+    std::vector<int> isr(F, 0), ro(F, 0);
+    int row = 1;
+    for (int i = 0; i < f.nf; ++i) {
+        isr[i] = f.isref[i];
+        ro[i] = row;
+        row += f.isref[i] ? 6 : 4;
+    }
+    int nf = f.nf, m = row;
+    HIPCHK(h, hipMemcpy(h->fv.nf + b, &nf, sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->fv.m + b, &m, sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->fv.isref + (size_t)b * F, isr.data(), F * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->fv.rowoff + (size_t)b * F, ro.data(), F * sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+
+__global__ void init_features_kernel(FilterView fv, int b, int count, const int* __restrict__ slots,
+                                     const double* __restrict__ sxy, double q1, double q2, double q3, double q4,
+                                     double inv_dinit)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const int i = slots[t], F = fv.F;
+    const long long f3 = (long long)b * 3 * F, f4 = (long long)b * 4 * F, f2 = (long long)b * 2 * F;
+    const double sx = sxy[2 * t], sy = sxy[2 * t + 1];
+    // Feature::initialize, src/ARC/feature.cpp:61-62,71,87-88
+    fv.pib[f3 + i] = sx; fv.pib[f3 + F + i] = sy; fv.pib[f3 + 2 * F + i] = inv_dinit;
+    for (int c = 0; c < 3; ++c) fv.anchor[f3 + (long long)c * F + i] = fv.X[3 * b + c];
+    fv.q0[f4 + i] = q1; fv.q0[f4 + F + i] = q2; fv.q0[f4 + 2 * F + i] = q3; fv.q0[f4 + 3 * F + i] = q4;
+    fv.pib0[f2 + i] = sx; fv.pib0[f2 + F + i] = sy;
+}
+
+__global__ void init_cov_kernel(double* P, int ld, long long stride, double pinit)
+{
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (t < 9) P[(long long)b * stride + (long long)t * ld + t] = (t < 3 || t >= 6) ? pinit * 1.0 : 1.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// covariance pipelines (all launches on one stream, no host synchronisation)
+// ------------------------------------------------------------------------------------------------
+int run_predict(slamk_handle* h, const double* qbw, const double* w, const double* acc, const double* dt,
+                hipStream_t st)
+{
+    const int B = h->B, nl = max_nl(h), ldn = h->ldn;
+    const long long sN = (long long)ldn * ldn;
+    h->last_nl = nl;
+    hipLaunchKernelGGL(build_F_kernel, dim3((nl + 63) / 64, (nl + 3) / 4, B), dim3(256), 0, st, h->fv, qbw, w, dt,
+                       h->Fm, nl);
+    hipLaunchKernelGGL(dynamics_kernel, dim3(B), dim3(256), 0, st, h->fv, qbw, w, acc, dt);
+    // T = P F^T ; P = F T + Q      (calcP, src/slam/main.cpp:526-530, G = I)
+    HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_NONE>(
+                  gargs(h->fv.P, ldn, sN, h->Fm, ldn, sN, h->T, ldn, sN, nl, nl, nl), B, st)));
+    HIPCHK(h, (launch_gemm<false, EPI_DIAG_ADD, false, TRI_NONE>(
+                  gargs(h->Fm, ldn, sN, h->T, ldn, sN, h->fv.P, ldn, sN, nl, nl, nl, 1.0, 0.0, h->fv.qdiag, ldn), B,
+                  st)));
+    return 0;
+}
+
+int run_cholesky_inverse(slamk_handle* h, int ml, hipStream_t st)
+{
+    const int B = h->B, ldm = h->ldm;
+    const long long sM = (long long)ldm * ldm;
+    const int NB = (ml <= 1024) ? 64 : 128;
+    // blocked right-looking Cholesky of S (lower) into L, diagonal-block inverses into Li
+    for (int j0 = 0; j0 < ml; j0 += NB) {
+        const int nb = std::min(NB, ml - j0);
+        if (NB == 64)
+            hipLaunchKernelGGL(potf2_inv_kernel<64>, dim3(B), dim3(256), (64 * 65 + 64) * sizeof(double), st, h->S,
+                               h->L, h->Li, ldm, sM, j0, nb);
+        else
+            hipLaunchKernelGGL(potf2_inv_kernel<128>, dim3(B), dim3(256), (128 * 129 + 128) * sizeof(double), st,
+                               h->S, h->L, h->Li, ldm, sM, j0, nb);
+        const int rem = ml - j0 - nb;
+        if (rem <= 0) break;
+        const long long o21 = (long long)(j0 + nb) * ldm + j0, o11 = (long long)j0 * ldm + j0;
+        const long long o22 = (long long)(j0 + nb) * ldm + (j0 + nb);
+        // L21 = S21 inv(L11)^T
+        HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_B_KLE_N>(
+                      gargs(h->S + o21, ldm, sM, h->Li + o11, ldm, sM, h->L + o21, ldm, sM, rem, nb, nb), B, st)));
+        // S22 -= L21 L21^T (lower tiles only)
+        HIPCHK(h, (launch_gemm<true, EPI_NONE, true, TRI_NONE>(
+                      gargs(h->L + o21, ldm, sM, h->L + o21, ldm, sM, h->S + o22, ldm, sM, rem, rem, nb, -1.0, 1.0),
+                      B, st)));
+    }
+    // inv(L) by recursive doubling on the block diagonal:
+    //   inv([[A,0],[Bk,C]]) = [[inv A, 0], [-inv C * Bk * inv A, inv C]]
+    // S's lower part is dead after the factorisation and holds the intermediate Bk * inv A.
+    for (int s = NB; s < ml; s *= 2) {
+        const int nfull = ml / (2 * s), r = ml - nfull * 2 * s;
+        for (int pass = 0; pass < 2; ++pass) {
+            int cnt, M, base;
+            if (pass == 0) { cnt = nfull; M = s; base = 0; }
+            else { cnt = (r > s) ? 1 : 0; M = r - s; base = nfull * 2 * s; }
+            if (cnt == 0) continue;
+            const long long oA = (long long)base * ldm + base;               // top-left block (s x s)
+            const long long oB = (long long)(base + s) * ldm + base;         // bottom-left (M x s)
+            const long long oC = (long long)(base + s) * ldm + (base + s);   // bottom-right (M x M)
+            const long long s2 = (long long)2 * s * (ldm + 1);
+            GemmArgs g1 = gargs(h->L + oB, ldm, sM, h->Li + oA, ldm, sM, h->S + oB, ldm, sM, M, s, s);
+            g1.sA2 = g1.sB2 = g1.sC2 = s2; g1.nb2 = cnt;
+            HIPCHK(h, (launch_gemm<false, EPI_NONE, false, TRI_B_KGE_N>(g1, B * cnt, st)));
+            GemmArgs g2 = gargs(h->Li + oC, ldm, sM, h->S + oB, ldm, sM, h->Li + oB, ldm, sM, M, s, M, -1.0, 0.0);
+            g2.sA2 = g2.sB2 = g2.sC2 = s2; g2.nb2 = cnt;
+            HIPCHK(h, (launch_gemm<false, EPI_NONE, false, TRI_A_KLE_M>(g2, B * cnt, st)));
+        }
+    }
+    return 0;
+}
+
+int run_update(slamk_handle* h, const double* qbw, const double* alt, const double* src, const double* refl,
+               int* applied, hipStream_t st)
+{
+    const int B = h->B, ldn = h->ldn, ldm = h->ldm;
+    const int nl = max_nl(h), ml = max_ml(h);
+    const long long sN = (long long)ldn * ldn, sNM = (long long)ldn * ldm, sMN = (long long)ldm * ldn,
+                    sM = (long long)ldm * ldm;
+    h->last_nl = nl; h->last_ml = ml;
+    int nfmax = 0;
+    for (const auto& f : h->hf) nfmax = std::max(nfmax, f.nf);
+    if (!src) src = h->fv.msrc;
+    if (!refl) refl = h->fv.mrefl;
+
+    hipLaunchKernelGGL(measure_kernel, dim3(std::max(1, (nfmax + 63) / 64), B), dim3(64), 0, st, h->fv, qbw, alt, src,
+                       refl, ml);
+    hipLaunchKernelGGL(build_H_kernel, dim3((nl + 63) / 64, (ml + 3) / 4, B), dim3(256), 0, st, h->fv, h->Hm, ml, nl);
+    // W = P H^T                                  (calcK, src/slam/main.cpp:545)
+    HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_NONE>(
+                  gargs(h->fv.P, ldn, sN, h->Hm, ldn, sMN, h->W, ldm, sNM, nl, ml, nl), B, st)));
+    // S = H W + R, lower tiles                   (:541-543)
+    HIPCHK(h, (launch_gemm<false, EPI_DIAG_ADD, true, TRI_NONE>(
+                  gargs(h->Hm, ldn, sMN, h->W, ldm, sNM, h->S, ldm, sM, ml, ml, nl, 1.0, 0.0, h->fv.rdiag, ldm), B,
+                  st)));
+    // S = L L^T, Li = inv(L)
+    int rc = run_cholesky_inverse(h, ml, st);
+    if (rc) return rc;
+    // K = W S^-1 = (W Li^T) Li                   (:547-550 solved by Cholesky instead of LU)
+    HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_B_KLE_N>(
+                  gargs(h->W, ldm, sNM, h->Li, ldm, sM, h->Y, ldm, sNM, nl, ml, ml), B, st)));
+    {
+        // K and, for the Joseph form, K R (R diagonal) from the same accumulators
+        GemmArgs g = gargs(h->Y, ldm, sNM, h->Li, ldm, sM, h->K, ldm, sNM, nl, ml, ml, 1.0, 0.0, h->fv.rdiag, ldm);
+        g.C2 = h->KR;
+        HIPCHK(h, (launch_gemm<false, EPI_DUAL_COLSCALE, false, TRI_B_KGE_N>(g, B, st)));
+    }
+    // A = I - K H                                (updateP, :563-565)
+    HIPCHK(h, (launch_gemm<false, EPI_EYE_MINUS, false, TRI_NONE>(
+                  gargs(h->K, ldm, sNM, h->Hm, ldn, sMN, h->Am, ldn, sN, nl, nl, ml), B, st)));
+    // AP = A P
+    HIPCHK(h, (launch_gemm<false, EPI_NONE, false, TRI_NONE>(
+                  gargs(h->Am, ldn, sN, h->fv.P, ldn, sN, h->AP, ldn, sN, nl, nl, nl), B, st)));
+    const double* presym = h->AP;
+    if (h->prm.update_form == 0) {
+        // Joseph: P = AP A^T + (K R) K^T
+        HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_NONE>(
+                      gargs(h->AP, ldn, sN, h->Am, ldn, sN, h->T, ldn, sN, nl, nl, nl), B, st)));
+        HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_NONE>(
+                      gargs(h->KR, ldm, sNM, h->K, ldm, sNM, h->T, ldn, sN, nl, nl, ml, 1.0, 1.0), B, st)));
+        presym = h->T;
+    }
+    // P = (P + P^T)/2                            (:567)
+    hipLaunchKernelGGL(symmetrize_kernel, dim3((nl + 31) / 32, (nl + 31) / 32, B), dim3(256), 0, st, presym, h->fv.P,
+                       ldn, sN, nl);
+    // dx = K e, gate, mean update                (main.cpp:228-232)
+    hipLaunchKernelGGL(gain_apply_kernel, dim3(B), dim3(256), 0, st, h->fv, h->K, h->dx, applied, ml);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// useful flops of one GEMM launch as the kernel executes it (tile skipping and k-range trimming
+// included, zero padding inside edge tiles excluded)
+double gemm_flops(int M, int N, int K, bool lower, int tri)
+{
+    const bool big = (M >= 512 && N >= 512);
+    const int BM = big ? 128 : 64, BN = BM;
+    double f = 0;
+    for (int m0 = 0; m0 < M; m0 += BM)
+        for (int n0 = 0; n0 < N; n0 += BN) {
+            if (lower && n0 > m0 + BM - 1) continue;
+            int kb = 0, ke = K;
+            if (tri == TRI_B_KLE_N) ke = std::min(K, n0 + BN);
+            if (tri == TRI_B_KGE_N) kb = std::min(K, n0);
+            if (tri == TRI_A_KLE_M) ke = std::min(K, m0 + BM);
+            f += 2.0 * std::min(BM, M - m0) * std::min(BN, N - n0) * std::max(0, ke - kb);
+        }
+    return f;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+void slamk_default_params(slamk_params* p)
+{
+    p->Q0 = 256; p->R0 = 32; p->qbias = 1e-5; p->p0 = 2; p->pinit = 1e-4;
+    p->alt_override = -1.34; p->use_alt_override = 1;
+    p->gate = 4; p->d_min = 0.1; p->d_max = 10e3; p->dinit = 100;
+    p->update_form = 0;
+}
+
+const char* slamk_last_error(const slamk_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int slamk_create(const slamk_params* p, int max_features, int batch, int device, slamk_handle** out)
+{
+    if (!out || max_features < 0 || batch < 1) return SLAMK_EINVAL;
+    slamk_handle* h = new slamk_handle();
+    if (p) h->prm = *p; else slamk_default_params(&h->prm);
+    h->B = batch; h->F = std::max(1, max_features); h->device = device;
+    h->ldn = pad16(9 + 3 * h->F);
+    h->ldm = pad16(1 + 6 * h->F);
+    h->hf.resize(batch);
+    *out = h;
+    HIPCHK(h, hipSetDevice(device));
+    const size_t B = batch, F = h->F, ldn = h->ldn, ldm = h->ldm;
+    FilterView& v = h->fv;
+    v.B = batch; v.F = h->F; v.ldn = h->ldn; v.ldm = h->ldm;
+    int rc = 0;
+    rc |= dalloc(h, &v.X, B * 3); rc |= dalloc(h, &v.V, B * 3); rc |= dalloc(h, &v.bias, B * 3);
+    rc |= dalloc(h, &v.old_pos, B * 3);
+    rc |= dalloc(h, &v.nf, B); rc |= dalloc(h, &v.m, B); rc |= dalloc(h, &v.status, B);
+    rc |= dalloc(h, &v.pib, B * 3 * F); rc |= dalloc(h, &v.anchor, B * 3 * F);
+    rc |= dalloc(h, &v.q0, B * 4 * F); rc |= dalloc(h, &v.pib0, B * 2 * F);
+    rc |= dalloc(h, &v.isref, B * F); rc |= dalloc(h, &v.rowoff, B * F);
+    rc |= dalloc(h, &v.msrc, B * 2 * F); rc |= dalloc(h, &v.mrefl, B * 2 * F);
+    rc |= dalloc(h, &v.P, B * ldn * ldn);
+    rc |= dalloc(h, &v.ha, B * ldm * 3); rc |= dalloc(h, &v.hb, B * ldm * 3); rc |= dalloc(h, &v.hcs, B * ldm);
+    rc |= dalloc(h, &v.e, B * ldm); rc |= dalloc(h, &v.rdiag, B * ldm); rc |= dalloc(h, &v.qdiag, B * ldn);
+    rc |= dalloc(h, &h->Fm, B * ldn * ldn); rc |= dalloc(h, &h->T, B * ldn * ldn);
+    rc |= dalloc(h, &h->Am, B * ldn * ldn); rc |= dalloc(h, &h->AP, B * ldn * ldn);
+    rc |= dalloc(h, &h->Hm, B * ldm * ldn);
+    rc |= dalloc(h, &h->W, B * ldn * ldm); rc |= dalloc(h, &h->Y, B * ldn * ldm);
+    rc |= dalloc(h, &h->K, B * ldn * ldm); rc |= dalloc(h, &h->KR, B * ldn * ldm);
+    rc |= dalloc(h, &h->S, B * ldm * ldm); rc |= dalloc(h, &h->L, B * ldm * ldm); rc |= dalloc(h, &h->Li, B * ldm * ldm);
+    rc |= dalloc(h, &h->dx, B * ldn);
+    rc |= dalloc(h, &h->qbw_d, B * 4); rc |= dalloc(h, &h->w_d, B * 3); rc |= dalloc(h, &h->acc_d, B * 3);
+    rc |= dalloc(h, &h->dt_d, B); rc |= dalloc(h, &h->alt_d, B); rc |= dalloc(h, &h->applied_d, B);
+    rc |= dalloc(h, &h->map_d, ldn); rc |= dalloc(h, &h->feat_tmp, 4 * F);
+    if (rc) return SLAMK_EHIP;
+    v.Q0 = h->prm.Q0; v.R0 = h->prm.R0; v.qbias = h->prm.qbias; v.gate = h->prm.gate;
+    v.inv_dmax = 1 / h->prm.d_max; v.inv_dmin = 1 / h->prm.d_min;
+    v.alt_override = h->prm.alt_override; v.use_alt_override = h->prm.use_alt_override;
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_kernel<128>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (128 * 129 + 128) * sizeof(double)));
+    hipLaunchKernelGGL(init_cov_kernel, dim3(batch), dim3(64), 0, 0, v.P, h->ldn, (long long)ldn * ldn, h->prm.pinit);
+    for (int b = 0; b < batch; ++b) {
+        int one = 1;
+        HIPCHK(h, hipMemcpy(v.m + b, &one, sizeof(int), hipMemcpyHostToDevice));
+    }
+    HIPCHK(h, hipDeviceSynchronize());
+    return SLAMK_OK;
+}
+
+int slamk_destroy(slamk_handle* h)
+{
+    if (!h) return SLAMK_EINVAL;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : h->allocs) (void)hipFree(p);
+    delete h;
+    return SLAMK_OK;
+}
+
+#define CHECK_B(h, b)                                                                  \
+    do {                                                                               \
+        if (!(h)) return SLAMK_EINVAL;                                                 \
+        if ((b) < 0 || (b) >= (h)->B) return fail(h, SLAMK_EINVAL, "filter index %d out of range", (b)); \
+    } while (0)
+
+int slamk_set_state(slamk_handle* h, int b, const double* X, const double* V, const double* bias)
+{
+    CHECK_B(h, b);
+    HIPCHK(h, hipSetDevice(h->device));
+    if (X) HIPCHK(h, hipMemcpy(h->fv.X + 3 * b, X, 24, hipMemcpyHostToDevice));
+    if (V) HIPCHK(h, hipMemcpy(h->fv.V + 3 * b, V, 24, hipMemcpyHostToDevice));
+    if (bias) HIPCHK(h, hipMemcpy(h->fv.bias + 3 * b, bias, 24, hipMemcpyHostToDevice));
+    return SLAMK_OK;
+}
+
+int slamk_get_state(slamk_handle* h, int b, double* X, double* V, double* bias)
+{
+    CHECK_B(h, b);
+    HIPCHK(h, hipSetDevice(h->device));
+    if (X) HIPCHK(h, hipMemcpy(X, h->fv.X + 3 * b, 24, hipMemcpyDeviceToHost));
+    if (V) HIPCHK(h, hipMemcpy(V, h->fv.V + 3 * b, 24, hipMemcpyDeviceToHost));
+    if (bias) HIPCHK(h, hipMemcpy(bias, h->fv.bias + 3 * b, 24, hipMemcpyDeviceToHost));
+    return SLAMK_OK;
+}
+
+int slamk_set_cov(slamk_handle* h, int b, const double* P, int n, int ld)
+{
+    CHECK_B(h, b);
+    if (!P || n != 9 + 3 * h->hf[b].nf || ld < n) return fail(h, SLAMK_EINVAL, "set_cov: n=%d does not match nf=%d", n, h->hf[b].nf);
+    HIPCHK(h, hipSetDevice(h->device));
+    double* dst = h->fv.P + (size_t)b * h->ldn * h->ldn;
+    HIPCHK(h, hipMemset(dst, 0, (size_t)h->ldn * h->ldn * sizeof(double)));
+    HIPCHK(h, hipMemcpy2D(dst, h->ldn * sizeof(double), P, ld * sizeof(double), n * sizeof(double), n, hipMemcpyHostToDevice));
+    return SLAMK_OK;
+}
+
+int slamk_get_cov(slamk_handle* h, int b, double* P, int n, int ld)
+{
+    CHECK_B(h, b);
+    if (!P || n != 9 + 3 * h->hf[b].nf || ld < n) return fail(h, SLAMK_EINVAL, "get_cov: n=%d does not match nf=%d", n, h->hf[b].nf);
+    HIPCHK(h, hipSetDevice(h->device));
+    const double* src = h->fv.P + (size_t)b * h->ldn * h->ldn;
+    HIPCHK(h, hipMemcpy2D(P, ld * sizeof(double), src, h->ldn * sizeof(double), n * sizeof(double), n, hipMemcpyDeviceToHost));
+    return SLAMK_OK;
+}
+
+int slamk_num_features(slamk_handle* h, int b) { CHECK_B(h, b); return h->hf[b].nf; }
+int slamk_num_rows(slamk_handle* h, int b) { CHECK_B(h, b); return h->hf[b].m(); }
+
+int slamk_set_features(slamk_handle* h, int b, int nf, const int32_t* id, const double* pib, const double* anchor,
+                       const double* q0, const double* pib0, const uint8_t* is_ref)
+{
+    CHECK_B(h, b);
+    if (nf < 0 || nf > h->F) return fail(h, SLAMK_ECAPACITY, "set_features: nf=%d exceeds max_features=%d", nf, h->F);
+    if (nf && (!id || !pib || !anchor || !q0 || !pib0 || !is_ref)) return fail(h, SLAMK_EINVAL, "set_features: null array");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int F = h->F;
+    HostFilter& f = h->hf[b];
+    f.nf = nf;
+    f.id.assign(id, id + nf);
+    f.isref.assign(is_ref, is_ref + nf);
+    std::vector<double> t3(3 * F, 0.0), t4(4 * F, 0.0), t2(2 * F, 0.0);
+    auto up = [&](double* dev, const double* src, int nc, std::vector<double>& tmp) -> int {
+        std::fill(tmp.begin(), tmp.end(), 0.0);
+        for (int i = 0; i < nf; ++i)
+            for (int c = 0; c < nc; ++c) tmp[(size_t)c * F + i] = src[(size_t)nc * i + c];
+        HIPCHK(h, hipMemcpy(dev + (size_t)b * nc * F, tmp.data(), (size_t)nc * F * sizeof(double), hipMemcpyHostToDevice));
+        return 0;
+    };
+    if (up(h->fv.pib, pib, 3, t3) || up(h->fv.anchor, anchor, 3, t3) || up(h->fv.q0, q0, 4, t4) ||
+        up(h->fv.pib0, pib0, 2, t2))
+        return SLAMK_EHIP;
+    return push_layout(h, b);
+}
+
+int slamk_get_features(slamk_handle* h, int b, int* nf_out, int32_t* id, double* pib, double* anchor, double* q0,
+                       double* pib0, uint8_t* is_ref)
+{
+    CHECK_B(h, b);
+    HIPCHK(h, hipSetDevice(h->device));
+    const HostFilter& f = h->hf[b];
+    const int F = h->F, nf = f.nf;
+    if (nf_out) *nf_out = nf;
+    if (id) std::copy(f.id.begin(), f.id.end(), id);
+    if (is_ref) std::copy(f.isref.begin(), f.isref.end(), is_ref);
+    auto down = [&](const double* dev, double* dst, int nc) -> int {
+        if (!dst) return 0;
+        std::vector<double> tmp((size_t)nc * F);
+        HIPCHK(h, hipMemcpy(tmp.data(), dev + (size_t)b * nc * F, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < nf; ++i)
+            for (int c = 0; c < nc; ++c) dst[(size_t)nc * i + c] = tmp[(size_t)c * F + i];
+        return 0;
+    };
+    if (down(h->fv.pib, pib, 3) || down(h->fv.anchor, anchor, 3) || down(h->fv.q0, q0, 4) || down(h->fv.pib0, pib0, 2))
+        return SLAMK_EHIP;
+    return SLAMK_OK;
+}
+
+// ---- image frame ------------------------------------------------------------------------------
+static int frame_one(slamk_handle* h, int b, const slamk_match* matches, int nmatch, const double quat[4])
+{
+    const int F = h->F, ldn = h->ldn;
+    HostFilter& f = h->hf[b];
+    // old_pos = X, depth clamp (main.cpp:168, states.cpp:91-103)
+    hipLaunchKernelGGL(frame_begin_kernel, dim3(1), dim3(256), 0, 0, h->fv, b);
+
+    // ---- association on the host mirror (States::update_features, states.cpp:104-200) ----
+    const int old_nf = f.nf;
+    std::vector<int32_t> ids = f.id;
+    std::vector<uint8_t> isr = f.isref;
+    std::vector<int> nomatch(old_nf, 1), srcslot(old_nf), fresh_of;   // fresh_of[slot] = match index or -1
+    for (int i = 0; i < old_nf; ++i) {
+        srcslot[i] = i;
+        for (int k = 0; k < nmatch; ++k)
+            if (ids[i] == matches[k].id) { nomatch[i] = 0; break; }
+    }
+    fresh_of.assign(old_nf, -1);
+    for (int k = 0; k < nmatch; ++k) {
+        bool found = false;
+        for (size_t i = 0; i < ids.size(); ++i)
+            if (ids[i] == matches[k].id) { found = true; break; }
+        if (found) continue;
+        const uint8_t ref = !(matches[k].rx == 0 && matches[k].ry == 0);   // projection::isRef, featureIO.h:36
+        int slot = -1;
+        for (size_t i = 0; i < ids.size(); ++i)
+            if (nomatch[i] != 0) { slot = (int)i; break; }
+        if (slot >= 0) {
+            ids[slot] = matches[k].id; isr[slot] = ref; nomatch[slot] = 0; srcslot[slot] = -1; fresh_of[slot] = k;
+        } else {
+            ids.push_back(matches[k].id); isr.push_back(ref); nomatch.push_back(0); srcslot.push_back(-1);
+            fresh_of.push_back(k);
+        }
+    }
+    // erase what is still unmatched, keeping order
+    std::vector<int32_t> nid; std::vector<uint8_t> nisr; std::vector<int> nsrc, nfresh;
+    for (size_t i = 0; i < ids.size(); ++i) {
+        if (nomatch[i] != 0) continue;
+        nid.push_back(ids[i]); nisr.push_back(isr[i]); nsrc.push_back(srcslot[i]); nfresh.push_back(fresh_of[i]);
+    }
+    const int nf = (int)nid.size();
+    if (nf > F) return fail(h, SLAMK_ECAPACITY, "frame: %d features exceed max_features=%d", nf, F);
+
+    bool identity = (nf == old_nf);
+    for (int i = 0; i < nf && identity; ++i) identity = (nsrc[i] == i);
+
+    if (!identity) {
+        // per-feature containers: copy out, gather back
+        struct Arr { double* p; int nc; } arrs[4] = {{h->fv.pib, 3}, {h->fv.anchor, 3}, {h->fv.q0, 4}, {h->fv.pib0, 2}};
+        std::vector<int> smap(std::max(1, nf));
+        for (int i = 0; i < nf; ++i) smap[i] = nsrc[i];
+        HIPCHK(h, hipMemcpy(h->map_d, smap.data(), smap.size() * sizeof(int), hipMemcpyHostToDevice));
+        for (auto& a : arrs) {
+            double* live = a.p + (size_t)b * a.nc * F;
+            HIPCHK(h, hipMemcpyAsync(h->feat_tmp, live, (size_t)a.nc * F * sizeof(double), hipMemcpyDeviceToDevice, 0));
+            if (nf) hipLaunchKernelGGL(gather_slots_kernel, dim3((nf + 255) / 256), dim3(256), 0, 0, h->feat_tmp, live,
+                                       h->map_d, F, nf, a.nc);
+        }
+        HIPCHK(h, hipDeviceSynchronize());
+        // covariance rows/cols: one gather through the state-index map
+        const int n_new = 9 + 3 * nf, nl = pad16(std::max(n_new, 9 + 3 * old_nf));
+        std::vector<int> imap(ldn, -2);
+        for (int c = 0; c < 6; ++c) imap[c] = c;
+        for (int i = 0; i < nf; ++i)
+            for (int c = 0; c < 3; ++c) imap[6 + 3 * i + c] = nsrc[i] >= 0 ? 6 + 3 * nsrc[i] + c : -1;
+        for (int c = 0; c < 3; ++c) imap[6 + 3 * nf + c] = 6 + 3 * old_nf + c;
+        HIPCHK(h, hipMemcpy(h->map_d, imap.data(), ldn * sizeof(int), hipMemcpyHostToDevice));
+        double* Pb = h->fv.P + (size_t)b * ldn * ldn;
+        double* Tb = h->T + (size_t)b * ldn * ldn;
+        hipLaunchKernelGGL(remap_cov_kernel, dim3((nl + 63) / 64, (nl + 3) / 4), dim3(256), 0, 0, Pb, Tb, h->map_d, ldn,
+                           nl, h->prm.p0);
+        HIPCHK(h, hipMemcpyAsync(Pb, Tb, (size_t)nl * ldn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+        HIPCHK(h, hipDeviceSynchronize());
+    }
+    f.nf = nf; f.id = nid; f.isref = nisr;
+    int rc = push_layout(h, b);
+    if (rc) return rc;
+    // new features: Feature(X, sense, match)  feature.cpp:41-91
+    std::vector<int> slots; std::vector<double> sxy;
+    for (int i = 0; i < nf; ++i)
+        if (nfresh[i] >= 0) { slots.push_back(i); sxy.push_back(matches[nfresh[i]].sx); sxy.push_back(matches[nfresh[i]].sy); }
+    if (!slots.empty()) {
+        int* slots_d = nullptr; double* sxy_d = nullptr;
+        HIPCHK(h, hipMalloc(&slots_d, slots.size() * sizeof(int)));
+        HIPCHK(h, hipMalloc(&sxy_d, sxy.size() * sizeof(double)));
+        HIPCHK(h, hipMemcpy(slots_d, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(sxy_d, sxy.data(), sxy.size() * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(init_features_kernel, dim3(((int)slots.size() + 63) / 64), dim3(64), 0, 0, h->fv, b,
+                           (int)slots.size(), slots_d, sxy_d, quat[0], quat[1], quat[2], quat[3], 1 / h->prm.dinit);
+        HIPCHK(h, hipDeviceSynchronize());
+        (void)hipFree(slots_d); (void)hipFree(sxy_d);
+    }
+    // keep the frame's observations in slot order (the id search of measurementModel, main.cpp:362-375)
+    std::vector<double> ms(2 * F, 0.0), mr(2 * F, 0.0);
+    for (int i = 0; i < nf; ++i) {
+        const slamk_match* mt = nullptr;
+        for (int k = 0; k < nmatch; ++k)
+            if (matches[k].id == nid[i]) { mt = &matches[k]; break; }
+        if (!mt) return fail(h, SLAMK_ENOMATCH, "Cannot find match.");
+        ms[i] = mt->sx; ms[F + i] = mt->sy;
+        mr[i] = mt->rx; mr[F + i] = mt->ry;
+    }
+    HIPCHK(h, hipMemcpy(h->fv.msrc + (size_t)b * 2 * F, ms.data(), 2 * F * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->fv.mrefl + (size_t)b * 2 * F, mr.data(), 2 * F * sizeof(double), hipMemcpyHostToDevice));
+    return SLAMK_OK;
+}
+
+int slamk_frame(slamk_handle* h, int b, const slamk_match* matches, int nmatch, const double quat[4])
+{
+    if (!h || nmatch < 0 || (nmatch && !matches) || !quat) return SLAMK_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (b >= 0) { CHECK_B(h, b); return frame_one(h, b, matches, nmatch, quat); }
+    for (int i = 0; i < h->B; ++i) {
+        int rc = frame_one(h, i, matches, nmatch, quat);
+        if (rc) return rc;
+    }
+    return SLAMK_OK;
+}
+
+int slamk_set_frame_values(slamk_handle* h, int b, const double* src2, const double* refl2)
+{
+    CHECK_B(h, b);
+    if (!src2 || !refl2) return SLAMK_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int F = h->F, nf = h->hf[b].nf;
+    std::vector<double> ms(2 * F, 0.0), mr(2 * F, 0.0);
+    for (int i = 0; i < nf; ++i) {
+        ms[i] = src2[2 * i]; ms[F + i] = src2[2 * i + 1];
+        mr[i] = refl2[2 * i]; mr[F + i] = refl2[2 * i + 1];
+    }
+    HIPCHK(h, hipMemcpy(h->fv.msrc + (size_t)b * 2 * F, ms.data(), 2 * F * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->fv.mrefl + (size_t)b * 2 * F, mr.data(), 2 * F * sizeof(double), hipMemcpyHostToDevice));
+    return SLAMK_OK;
+}
+
+// ---- predict / update ----------------------------------------------------------------------------
+int slamk_frame_begin_dev(slamk_handle* h, void* stream)
+{
+    if (!h) return SLAMK_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(frame_begin_kernel, dim3(h->B), dim3(256), 0, (hipStream_t)stream, h->fv, -1);
+    HIPCHK(h, hipGetLastError());
+    return SLAMK_OK;
+}
+
+int slamk_predict_dev(slamk_handle* h, const double* qbw_dev, const double* w_dev, const double* acc_dev,
+                      const double* dt_dev, void* stream)
+{
+    if (!h || !qbw_dev || !w_dev || !acc_dev || !dt_dev) return SLAMK_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    return run_predict(h, qbw_dev, w_dev, acc_dev, dt_dev, (hipStream_t)stream);
+}
+
+int slamk_update_dev(slamk_handle* h, const double* qbw_dev, const double* alt_dev, const double* src_dev,
+                     const double* refl_dev, int32_t* applied_dev, void* stream)
+{
+    if (!h || !qbw_dev) return SLAMK_EINVAL;
+    if (!alt_dev && !h->prm.use_alt_override) return fail(h, SLAMK_EINVAL, "update: alt required without alt_override");
+    HIPCHK(h, hipSetDevice(h->device));
+    return run_update(h, qbw_dev, alt_dev ? alt_dev : h->alt_d, src_dev, refl_dev, applied_dev, (hipStream_t)stream);
+}
+
+int slamk_sync(slamk_handle* h, void* stream)
+{
+    if (!h) return SLAMK_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    std::vector<int> st(h->B);
+    HIPCHK(h, hipMemcpy(st.data(), h->fv.status, h->B * sizeof(int), hipMemcpyDeviceToHost));
+    for (int b = 0; b < h->B; ++b)
+        if (st[b] & 1) {
+            HIPCHK(h, hipMemset(h->fv.status, 0, h->B * sizeof(int)));
+            return fail(h, SLAMK_EREFL, "filter %d: reflection rows of H, R and e disagree (zero reflection observation or innovation)", b);
+        }
+    return SLAMK_OK;
+}
+
+int slamk_predict(slamk_handle* h, const double* qbw, const double* w, const double* acc, const double* dt)
+{
+    if (!h || !qbw || !w || !acc || !dt) return SLAMK_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t B = h->B;
+    HIPCHK(h, hipMemcpy(h->qbw_d, qbw, B * 32, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->w_d, w, B * 24, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->acc_d, acc, B * 24, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->dt_d, dt, B * 8, hipMemcpyHostToDevice));
+    int rc = run_predict(h, h->qbw_d, h->w_d, h->acc_d, h->dt_d, 0);
+    if (rc) return rc;
+    HIPCHK(h, hipDeviceSynchronize());
+    return SLAMK_OK;
+}
+
+int slamk_update(slamk_handle* h, const double* qbw, const double* alt, int* applied)
+{
+    if (!h || !qbw) return SLAMK_EINVAL;
+    if (!alt && !h->prm.use_alt_override) return fail(h, SLAMK_EINVAL, "update: alt required without alt_override");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t B = h->B;
+    HIPCHK(h, hipMemcpy(h->qbw_d, qbw, B * 32, hipMemcpyHostToDevice));
+    if (alt) HIPCHK(h, hipMemcpy(h->alt_d, alt, B * 8, hipMemcpyHostToDevice));
+    int rc = run_update(h, h->qbw_d, h->alt_d, nullptr, nullptr, h->applied_d, 0);
+    if (rc) return rc;
+    rc = slamk_sync(h, 0);
+    if (applied) HIPCHK(h, hipMemcpy(applied, h->applied_d, B * sizeof(int), hipMemcpyDeviceToHost));
+    return rc;
+}
+
+// ---- introspection -----------------------------------------------------------------------------------
+int slamk_debug_get(slamk_handle* h, int b, double* H, double* L, double* K, double* e)
+{
+    CHECK_B(h, b);
+    HIPCHK(h, hipSetDevice(h->device));
+    const int n = 9 + 3 * h->hf[b].nf, m = h->hf[b].m();
+    const size_t ldn = h->ldn, ldm = h->ldm;
+    if (H) HIPCHK(h, hipMemcpy2D(H, n * 8, h->Hm + b * ldm * ldn, ldn * 8, n * 8, m, hipMemcpyDeviceToHost));
+    if (L) HIPCHK(h, hipMemcpy2D(L, m * 8, h->L + b * ldm * ldm, ldm * 8, m * 8, m, hipMemcpyDeviceToHost));
+    if (K) HIPCHK(h, hipMemcpy2D(K, m * 8, h->K + b * ldn * ldm, ldm * 8, m * 8, n, hipMemcpyDeviceToHost));
+    if (e) HIPCHK(h, hipMemcpy(e, h->fv.e + b * ldm, m * 8, hipMemcpyDeviceToHost));
+    return SLAMK_OK;
+}
+
+int slamk_debug_get_F(slamk_handle* h, int b, double* F)
+{
+    CHECK_B(h, b);
+    HIPCHK(h, hipSetDevice(h->device));
+    const int n = 9 + 3 * h->hf[b].nf;
+    const size_t ldn = h->ldn;
+    HIPCHK(h, hipMemcpy2D(F, n * 8, h->Fm + b * ldn * ldn, ldn * 8, n * 8, n, hipMemcpyDeviceToHost));
+    return SLAMK_OK;
+}
+
+int slamk_dgemm_dev(int trans_b, int M, int N, int K, double alpha, const double* A_dev, int lda, long long strideA,
+                    const double* B_dev, int ldb, long long strideB, double beta, double* C_dev, int ldc,
+                    long long strideC, int batch, void* stream)
+{
+    if ((M | N | K) & 15) return SLAMK_EINVAL;
+    GemmArgs g = gargs(A_dev, lda, strideA, B_dev, ldb, strideB, C_dev, ldc, strideC, M, N, K, alpha, beta);
+    hipError_t e = trans_b ? launch_gemm<true, EPI_NONE, false, TRI_NONE>(g, batch, (hipStream_t)stream)
+                           : launch_gemm<false, EPI_NONE, false, TRI_NONE>(g, batch, (hipStream_t)stream);
+    return e == hipSuccess ? SLAMK_OK : SLAMK_EHIP;
+}
+
+int slamk_mfma_f64_probe(int iters, double* tflops)
+{
+    if (iters < 1 || !tflops) return SLAMK_EINVAL;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return SLAMK_EHIP;
+    double* out = nullptr;
+    if (hipMalloc(&out, 8) != hipSuccess) return SLAMK_EHIP;
+    const int blocks = prop.multiProcessorCount * 2;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, 0, out, 16);
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, 0, out, iters);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)blocks * 4 * iters * 8 * 2.0 * 16 * 16 * 4;
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(out);
+    return SLAMK_OK;
+}
+
+double slamk_flops_predict(int n)
+{
+    const int nl = pad16(n);
+    return 2 * gemm_flops(nl, nl, nl, false, TRI_NONE);
+}
+
+double slamk_flops_update(int n, int m, int update_form)
+{
+    const int nl = pad16(n), ml = pad16(m);
+    double f = 0;
+    f += gemm_flops(nl, ml, nl, false, TRI_NONE);              // W
+    f += gemm_flops(ml, ml, nl, true, TRI_NONE);               // S
+    const int NB = (ml <= 1024) ? 64 : 128;
+    for (int j0 = 0; j0 < ml; j0 += NB) {
+        const int nb = std::min(NB, ml - j0), rem = ml - j0 - nb;
+        f += (double)nb * nb * nb / 3;                          // diagonal block factor
+        f += (double)nb * nb * nb / 3;                          // and its inverse
+        if (rem <= 0) break;
+        f += gemm_flops(rem, nb, nb, false, TRI_B_KLE_N);
+        f += gemm_flops(rem, rem, nb, true, TRI_NONE);
+    }
+    for (int s = NB; s < ml; s *= 2) {
+        const int nfull = ml / (2 * s), r = ml - nfull * 2 * s;
+        f += nfull * (gemm_flops(s, s, s, false, TRI_B_KGE_N) + gemm_flops(s, s, s, false, TRI_A_KLE_M));
+        if (r > s) f += gemm_flops(r - s, s, s, false, TRI_B_KGE_N) + gemm_flops(r - s, s, r - s, false, TRI_A_KLE_M);
+    }
+    f += gemm_flops(nl, ml, ml, false, TRI_B_KLE_N);           // Y
+    f += gemm_flops(nl, ml, ml, false, TRI_B_KGE_N);           // K
+    f += gemm_flops(nl, nl, ml, false, TRI_NONE);              // A = I - K H
+    f += gemm_flops(nl, nl, nl, false, TRI_NONE);              // A P
+    if (update_form == 0) {
+        f += gemm_flops(nl, nl, nl, false, TRI_NONE);          // (A P) A^T
+        f += gemm_flops(nl, nl, ml, false, TRI_NONE);          // (K R) K^T
+    }
+    f += 2.0 * n * m;                                          // K e
+    return f;
+}
+
+}  // extern "C"
