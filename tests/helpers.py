@@ -24,9 +24,10 @@ def stream_inputs(stream, noise_seed):
     return out
 
 
-def run_oracle(stream, noise_seed=7, params=None, init_state=True):
+def run_oracle(stream, noise_seed=7, params=None, init_state=True, inp=None):
     """Returns list of snapshots after every loop iteration."""
-    inp = stream_inputs(stream, noise_seed)
+    if inp is None:
+        inp = stream_inputs(stream, noise_seed)
     f = orc.Filter(params)
     u, quat, ang, acc, dt, matches = inp[0]
     if init_state and stream.init_pos is not None:

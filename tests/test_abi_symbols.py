@@ -1,0 +1,41 @@
+"""CPU: the C-ABI library loads and exports every symbol include/slamk.h declares."""
+import ctypes
+import os
+import re
+
+from slam_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "slamk.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(slamk_[a-z0-9_]+)\s*\(", txt, flags=re.I)))
+
+
+def test_header_symbols_are_exported():
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert not missing, missing
+
+
+def test_python_prototypes_cover_the_header():
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+
+
+def test_default_params_match_reference_constants():
+    p = _lib.Params()
+    _lib.lib().slamk_default_params(ctypes.byref(p))
+    assert (p.Q0, p.R0, p.qbias, p.p0, p.pinit) == (256, 32, 1e-5, 2, 1e-4)
+    assert (p.alt_override, p.use_alt_override, p.gate, p.d_min, p.d_max, p.dinit) == (-1.34, 1, 4, 0.1, 10e3, 100)
+
+
+def test_flop_model_is_close_to_dense_formula():
+    # executed flops (tile skipping, triangular trimming) stay within the dense Cholesky+Joseph model
+    n, m = 105, 161
+    dense = 8 * n**3 + 6 * n * n * m + 4 * n * m * m + m**3 / 3 + 2 * n * m
+    ex = _lib.lib().slamk_flops_predict(n) + _lib.lib().slamk_flops_update(n, m, 0)
+    assert 0.8 * dense < ex < 1.6 * dense

@@ -1,0 +1,295 @@
+"""GPU: the HIP path through the C ABI against the CPU oracle.
+
+Bar: feature ids / slot order bit-exact; X, V, pib, P within 1e-9 relative (fp64) of the oracle
+on the same inputs; size-independent properties at the full benchmark sizes.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from slam_amd import ekf, synth, _lib
+import helpers
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def compare_snaps(so, sg, tol=TOL):
+    assert len(so) == len(sg)
+    worst = 0.0
+    for k, (a, b) in enumerate(zip(so, sg)):
+        assert a["ids"] == b["ids"], "association differs at step %d" % k
+        assert a["applied"] == b["applied"], "gate differs at step %d" % k
+        for key in ("X", "V", "pib", "P"):
+            e = helpers.rel_err(b[key], a[key])
+            assert e < tol, "step %d %s rel err %.3e" % (k, key, e)
+            worst = max(worst, e)
+        assert "%0.5f,%0.5f" % a["xy"] == "%0.5f,%0.5f" % b["xy"]
+    return worst
+
+
+# ------------------------------------------------------------------------------------------
+def test_dgemm_kernel_against_numpy():
+    torch = _torch()
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    for (M, N, K, batch) in [(64, 64, 64, 1), (112, 208, 112, 3), (208, 208, 112, 2), (640, 528, 96, 1),
+                             (1024, 512, 512, 1), (16, 16, 16, 5)]:
+        for tb in (0, 1):
+            A = rng.standard_normal((batch, M, K))
+            Bm = rng.standard_normal((batch, N, K) if tb else (batch, K, N))
+            C0 = rng.standard_normal((batch, M, N))
+            dA, dB, dC = (torch.from_numpy(x).cuda() for x in (A, Bm, C0))
+            rc = L.slamk_dgemm_dev(tb, M, N, K, 0.5, dA.data_ptr(), K, M * K, dB.data_ptr(), K if tb else N,
+                                   Bm.shape[1] * Bm.shape[2], -2.0, dC.data_ptr(), N, M * N, batch, None)
+            assert rc == 0
+            torch.cuda.synchronize()
+            ref = 0.5 * np.einsum("bmk,bnk->bmn" if tb else "bmk,bkn->bmn", A, Bm) - 2.0 * C0
+            assert helpers.rel_err(dC.cpu().numpy(), ref) < 1e-13, (M, N, K, batch, tb)
+    # operand-order check with structured data: A = I, asymmetric B
+    n = 64
+    A = np.eye(n)
+    Bm = np.arange(n * n, dtype=np.float64).reshape(n, n)
+    dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(Bm).cuda()
+    dC = torch.zeros(n, n, dtype=torch.float64, device="cuda")
+    L.slamk_dgemm_dev(0, n, n, n, 1.0, dA.data_ptr(), n, 0, dB.data_ptr(), n, 0, 0.0, dC.data_ptr(), n, 0, 1, None)
+    torch.cuda.synchronize()
+    assert np.array_equal(dC.cpu().numpy(), Bm)
+    L.slamk_dgemm_dev(1, n, n, n, 1.0, dA.data_ptr(), n, 0, dB.data_ptr(), n, 0, 0.0, dC.data_ptr(), n, 0, 1, None)
+    torch.cuda.synchronize()
+    assert np.array_equal(dC.cpu().numpy(), Bm.T)
+
+
+@pytest.mark.parametrize("nf,form", [(5, 0), (20, 0), (20, 1), (32, 0)])
+def test_single_filter_stream_parity(nf, form):
+    st = synth.gen_stream(seed=10 + nf, nf=nf, steps=61, churn=True, drop_at=21, drop_count=min(3, nf - 1),
+                          add_at=42, add_count=3)
+    so, _ = helpers.run_oracle(st)
+    p = ekf.default_params()
+    p.update_form = form
+    fb = ekf.FilterBatch(max_features=nf + 4, batch=1, params=p)
+    sg = helpers.run_gpu(st, fb)
+    worst = compare_snaps(so, sg)
+    nfs = {len(s["ids"]) for s in sg}
+    assert len(nfs) > 1                      # the stream really exercised insert / delete
+    print("nf=%d form=%d worst rel err %.2e" % (nf, form, worst))
+
+
+def test_per_function_parity():
+    """F, H, innovation, Cholesky factor and gain of one step against the oracle's functions."""
+    st = synth.gen_stream(seed=4, nf=14, steps=7, churn=False)
+    inp = helpers.stream_inputs(st, 7)
+    f = orc.Filter()
+    f.X = st.init_pos
+    fb = ekf.FilterBatch(max_features=14, batch=1)
+    fb.set_state(0, X=st.init_pos)
+    u, quat, ang, acc, dt, matches = inp[0]
+    f.update_features(matches, quat)
+    f.old_pos[:] = f.X
+    fb.frame(0, matches, quat)
+    for k in (1, 2):
+        u, quat, ang, acc, dt, matches = inp[k]
+        f.step(u, orc.make_sensors(quat=quat, acc=acc, ang=ang), dt, matches)
+        fb.predict(quat, ang, acc, [dt])
+    u, quat, ang, acc, dt, matches = inp[3]
+    assert u & orc.IMG
+    s = orc.make_sensors(quat=quat, acc=acc, ang=ang)
+    f.old_pos[:] = f.X
+    f.update_features(matches, quat)
+    F = f.motion_jacobian(s, dt)
+    f.dynamics_step(s, dt)
+    meas, hmu, H, ref = f.measurement_model(f.old_pos, -1.34, matches, quat)
+    P = orc.calc_p(f.P, F, orc.init_q_diag(f.nf, dt))
+    rd = orc.init_r_diag(ref)
+    K = orc.calc_k(H, P, rd)
+    fb.frame(0, matches, quat)
+    fb.predict(quat, ang, acc, [dt])
+    assert helpers.rel_err(fb.debug_get_F(0), F) < 1e-14
+    assert helpers.rel_err(fb.get_cov(0), P) < 1e-13
+    assert helpers.rel_err(fb.state_vector(0), f.state_vector()) < 1e-14
+    fb.update(quat)
+    d = fb.debug_get(0)
+    assert d["H"].shape == H.shape
+    assert helpers.rel_err(d["H"], H) < 1e-13
+    assert np.array_equal(d["H"] == 0, H == 0)              # same sparsity pattern
+    assert helpers.rel_err(d["e"], meas - hmu) < 1e-13
+    S = H @ P @ H.T + np.diag(rd)
+    assert helpers.rel_err(np.tril(d["L"]), np.linalg.cholesky(S)) < 1e-12
+    assert helpers.rel_err(d["K"], K) < 1e-11
+
+
+def test_reference_jacobian_golden_through_the_kernel():
+    """tests/golden/jacobian_h.json (values of the reference's closed-form text) vs measure_kernel."""
+    g = json.load(open(os.path.join(G, "jacobian_h.json")))
+    fh = float.fromhex
+    fb = ekf.FilterBatch(max_features=1, batch=1)
+    worst = 0.0
+    for c in g["cases"][:48]:
+        v = {k: np.array([fh(x) for x in c[k]]) for k in c}
+        fb.set_features(0, [7], v["pib"], v["anchor"], v["q0"], v["pib"][:2], [1])
+        fb.set_state(0, X=v["X"], V=np.zeros(3))
+        fb.set_cov(0, np.eye(12))
+        fb.set_frame_values(0, [0.1, 0.2], [0.3, 0.4])
+        fb.update(v["qbw"])
+        H = fb.debug_get(0)["H"]
+        Hb, Hi = v["Hb"].reshape(4, 6), v["Hi"].reshape(4, 3)
+        got_b, got_i = H[3:7, 0:6], H[3:7, 6:9]
+        for got, ref in ((got_b, Hb), (got_i, Hi)):
+            worst = max(worst, np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))))
+    assert worst < 1e-12, worst
+
+
+def test_batch_of_independent_filters():
+    """Filters of one batch see the same sensors but independent pixel noise; each must follow
+    its own oracle run."""
+    B, nf = 6, 9
+    st = synth.gen_stream(seed=21, nf=nf, steps=16, churn=False)
+    fb = ekf.FilterBatch(max_features=nf, batch=B)
+    oracles, snaps_o = [], []
+    for b in range(B):
+        so, _ = helpers.run_oracle(st, noise_seed=1000 + b)
+        snaps_o.append(so)
+    inps = [helpers.stream_inputs(st, 1000 + b) for b in range(B)]
+    for b in range(B):
+        fb.set_state(b, X=st.init_pos)
+        fb.frame(b, inps[b][0][5], inps[b][0][1])
+    for k in range(1, len(st.steps)):
+        u, quat, ang, acc, dt, _ = inps[0][k]
+        if u & orc.IMG:
+            for b in range(B):
+                fb.frame(b, inps[b][k][5], quat)
+        fb.predict(np.tile(quat, B), np.tile(ang, B), np.tile(acc, B), np.full(B, dt))
+        if u & orc.IMG:
+            applied = fb.update(np.tile(quat, B))
+        for b in range(B):
+            a = snaps_o[b][k - 1]
+            assert helpers.rel_err(fb.get_cov(b), a["P"]) < TOL
+            assert helpers.rel_err(fb.state_vector(b)[:-3], np.concatenate([a["X"], a["V"], a["pib"].ravel()])) < TOL
+            if u & orc.IMG:
+                assert applied[b] == a["applied"]
+
+
+def test_mixed_feature_counts_in_one_batch():
+    """Filters with different nf share one launch (dimensions are padded to the batch maximum)."""
+    sts = [synth.gen_stream(seed=30 + i, nf=nf, steps=7, churn=False) for i, nf in enumerate((4, 11, 7))]
+    B = len(sts)
+    fb = ekf.FilterBatch(max_features=11, batch=B)
+    inps = [helpers.stream_inputs(st, 5) for st in sts]
+    so = [helpers.run_oracle(st, noise_seed=5)[0] for st in sts]
+    for b in range(B):
+        fb.set_state(b, X=sts[b].init_pos)
+        fb.frame(b, inps[b][0][5], inps[b][0][1])
+    for k in range(1, 7):
+        img = inps[0][k][0] & orc.IMG
+        q = np.concatenate([inps[b][k][1] for b in range(B)])
+        w = np.concatenate([inps[b][k][2] for b in range(B)])
+        a = np.concatenate([inps[b][k][3] for b in range(B)])
+        dt = np.array([inps[b][k][4] for b in range(B)])
+        if img:
+            for b in range(B):
+                fb.frame(b, inps[b][k][5], inps[b][k][1])
+        fb.predict(q, w, a, dt)
+        if img:
+            fb.update(q)
+        for b in range(B):
+            assert helpers.rel_err(fb.get_cov(b), so[b][k - 1]["P"]) < TOL
+
+
+def test_error_paths():
+    fb = ekf.FilterBatch(max_features=3, batch=1)
+    q = [0, 0, 0, 1]
+    with pytest.raises(ekf.SlamkError) as ei:
+        fb.frame(0, [(i, 0.1 * i, 0.1, 0, 0) for i in range(5)], q)
+    assert ei.value.code == _lib.SLAMK_ECAPACITY
+    # a feature initialised with a reflection whose observation later is (0,0): the reference
+    # aborts on the H / R / e row mismatch (main.cpp:211-218,353; view.cpp:17,39)
+    fb = ekf.FilterBatch(max_features=3, batch=1)
+    fb.frame(0, [(1, 0.1, 0.1, 0.1, 0.3), (2, 0.2, -0.1, 0, 0)], q)
+    fb.predict(q, [0, 0, 0], [0, 0, 0], [0.1])
+    fb.frame(0, [(1, 0.1, 0.1, 0, 0), (2, 0.2, -0.1, 0, 0)], q)
+    with pytest.raises(ekf.SlamkError) as ei:
+        fb.update(q)
+    assert ei.value.code == _lib.SLAMK_EREFL
+    with pytest.raises(ekf.SlamkError):
+        fb.set_cov(0, np.eye(9))            # n must match the feature count
+
+
+def test_gate_rejects_mean_update_but_not_covariance():
+    """main.cpp:230-232: P is updated even when sum|V - dV| >= gate."""
+    st = synth.gen_stream(seed=8, nf=6, steps=4, churn=False)
+    inp = helpers.stream_inputs(st, 3)
+    p = ekf.default_params()
+    p.gate = 1e-6
+    po = orc.default_params()
+    po.gate = 1e-6
+    f = orc.Filter(po)
+    f.X = st.init_pos
+    fb = ekf.FilterBatch(max_features=6, batch=1, params=p)
+    fb.set_state(0, X=st.init_pos)
+    f.update_features(inp[0][5], inp[0][1])
+    f.old_pos[:] = f.X
+    fb.frame(0, inp[0][5], inp[0][1])
+    for k in (1, 2, 3):
+        u, quat, ang, acc, dt, matches = inp[k]
+        rc, xy, applied = f.step(u, orc.make_sensors(quat=quat, acc=acc, ang=ang), dt, matches)
+        if u & orc.IMG:
+            fb.frame(0, matches, quat)
+        fb.predict(quat, ang, acc, [dt])
+        if u & orc.IMG:
+            ap = fb.update(quat)[0]
+            assert ap == applied == 0
+    assert helpers.rel_err(fb.get_cov(0), f.P) < TOL
+    assert helpers.rel_err(fb.state_vector(0), f.state_vector()) < TOL
+
+
+def test_large_map_against_oracle():
+    """nf = 220 (n = 669, m > 1024): 128-wide tiles, 128-wide Cholesky panels, recursive inverse."""
+    nf = 220
+    st = synth.gen_stream(seed=2, nf=nf, steps=4, churn=False)
+    so, _ = helpers.run_oracle(st)
+    fb = ekf.FilterBatch(max_features=nf, batch=1)
+    sg = helpers.run_gpu(st, fb)
+    assert fb.num_rows(0) > 1024
+    compare_snaps(so, sg)
+
+
+def test_full_size_batch_properties():
+    """4096 filters x 32 features (the benchmark shape): a sample of filters against the oracle and
+    symmetry / finiteness / positive diagonal of every covariance."""
+    torch = _torch()
+    B, nf = 4096, 32
+    st = synth.gen_stream(seed=1, nf=nf, steps=4, churn=False, image_every=1)
+    fb = ekf.FilterBatch(max_features=nf, batch=B)
+    sample = [0, 1, 2047, 4095]
+    inps = {b: helpers.stream_inputs(st, 1000 + b) for b in sample}
+    base = helpers.stream_inputs(st, 999)
+    for b in sample:
+        inps[b][0] = base[0]                  # every filter is initialised from the same first frame
+    so = {b: helpers.run_oracle(st, inp=inps[b])[0] for b in sample}
+    for b in range(B):
+        fb.set_state(b, X=st.init_pos)
+    fb.frame(-1, base[0][5], base[0][1])
+    for k in range(1, 4):
+        u, quat, ang, acc, dt, matches = base[k]
+        fb.frame(-1, matches, quat)
+        for b in sample:
+            fb.frame(b, inps[b][k][5], quat)
+        fb.predict(np.tile(quat, B), np.tile(ang, B), np.tile(acc, B), np.full(B, dt))
+        fb.update(np.tile(quat, B))
+        for b in sample:
+            assert helpers.rel_err(fb.get_cov(b), so[b][k - 1]["P"]) < TOL
+    for b in (3, 100, 3000):
+        P = fb.get_cov(b)
+        assert np.all(np.isfinite(P)) and np.array_equal(P, P.T) and np.all(np.diag(P) > 0)
+        assert np.linalg.eigvalsh(P).min() > 0
