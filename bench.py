@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Benchmark of the EKF predict/update hot path on MI355X.
+
+Workload (BASELINE.json configs[2]): batched Monte Carlo, 4096 independent filters x 32
+features per GPU (n = 105, m = 161 with half of the features reflective), synthetic
+sensor_emu-style data.  One step = one loop iteration WITH an image for every filter of the
+batch: frame begin (old_pos, depth clamp), predict (F, dynamics, P = F P F^T + Q) and update
+(measurement model + Jacobian, S, Cholesky gain, Joseph covariance update, gated mean update).
+All inputs of every step are resident in HBM before the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: independent filters are sharded over ranks (B filters per rank, weak scaling), no
+data-path collective; torch.distributed (RCCL) is only used for the barrier and the MAX of the
+per-rank times.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X: 256 CU x 2.4 GHz x 128 fp64 FLOP/clk/CU (v_mfma_f64_16x16x4_f64)
+
+
+def build_inputs(torch, dev, B, nf, nsteps, rank):
+    """Truth stream shared by all filters, independent pixel noise per filter and step."""
+    from slam_amd import synth
+    st = synth.gen_stream(seed=1, nf=nf, steps=nsteps + 1, churn=False, image_every=1, ref_fraction=0.5)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1000 + rank)
+    steps = []
+    for k in range(1, nsteps + 1):
+        s, prev = st.steps[k], st.steps[k - 1]
+        one = lambda v: torch.tensor(np.tile(np.asarray(v, dtype=np.float64), (B, 1)), device=dev)
+        src = torch.tensor(s.src.T.copy(), device=dev)            # [2][F]
+        refl = torch.tensor(s.refl.T.copy(), device=dev)
+        has = (refl != 0).to(torch.float64)
+        srcb = src.unsqueeze(0) + st.noise * torch.randn((B, 2, nf), generator=g, device=dev, dtype=torch.float64)
+        reflb = refl.unsqueeze(0) + st.noise * torch.randn((B, 2, nf), generator=g, device=dev, dtype=torch.float64) * has
+        steps.append({
+            "qbw": one(s.quat), "w": one(s.ang), "acc": one(s.acc),
+            "dt": torch.full((B,), s.t - prev.t, device=dev, dtype=torch.float64),
+            "src": srcb.contiguous(), "refl": reflb.contiguous(),
+        })
+    return st, steps
+
+
+def first_frame(st):
+    s = st.steps[0]
+    return [(int(s.ids[i]), s.src[i, 0], s.src[i, 1], s.refl[i, 0], s.refl[i, 1]) for i in range(len(s.ids))]
+
+
+def cpu_baseline(st, steps, nf, k0, k1, budget_s=15.0):
+    """The CPU restatement (oracle/, 1 thread, dense products + LU as the reference) on a bounded
+    sample of the same workload: the first `cnt` filters of rank 0 over the timed steps."""
+    from oracle import oracle as orc
+    done, t_total, cnt = 0, 0.0, 0
+    host = [{k: v[:8].cpu().numpy() for k, v in s.items()} for s in steps]
+    while t_total < budget_s and cnt < 8:
+        f = orc.Filter()
+        f.X = st.init_pos
+        f.update_features(first_frame(st), st.steps[0].quat)
+        f.old_pos[:] = f.X
+        ids = [int(i) for i in st.steps[0].ids]
+        for k, s in enumerate(host):
+            m = [(ids[i], s["src"][cnt, 0, i], s["src"][cnt, 1, i], s["refl"][cnt, 0, i], s["refl"][cnt, 1, i])
+                 for i in range(nf)]
+            sens = orc.make_sensors(quat=s["qbw"][cnt], acc=s["acc"][cnt], ang=s["w"][cnt])
+            u = orc.ACC | orc.ANG | orc.QUAT | orc.IMG
+            t0 = time.perf_counter()
+            rc, _, _ = f.step(u, sens, float(s["dt"][cnt]), m)
+            t1 = time.perf_counter()
+            assert rc == 0
+            if k0 <= k < k1:
+                t_total += t1 - t0
+                done += 1
+        cnt += 1
+    return {"value": done / t_total, "unit": "EKF updates/s", "cores": 1, "kind": "port",
+            "sample": "%d filters x %d steps (nf=%d) of the same batch, oracle/ekf_oracle.c orc_step, 1 thread" % (cnt, k1 - k0, nf)}
+
+
+def single_filter_latency(torch, dev, nf=20, iters=40):
+    """configs[1]: one filter, 20 features, latency of one predict+update on one GPU (host-driven)."""
+    from slam_amd import ekf
+    st, steps = build_inputs(torch, dev, 1, nf, iters + 5, 0)
+    fb = ekf.FilterBatch(max_features=nf, batch=1, device=dev.index or 0)
+    fb.set_state(0, X=st.init_pos)
+    fb.frame(0, first_frame(st), st.steps[0].quat)
+    s0 = torch.cuda.Stream(device=dev)
+    def run(k):
+        s = steps[k]
+        fb.frame_begin_dev(s0.cuda_stream)
+        fb.predict_dev(s["qbw"].data_ptr(), s["w"].data_ptr(), s["acc"].data_ptr(), s["dt"].data_ptr(), s0.cuda_stream)
+        fb.update_dev(s["qbw"].data_ptr(), None, s["src"].data_ptr(), s["refl"].data_ptr(), None, s0.cuda_stream)
+    for k in range(5):
+        run(k)
+    fb.sync(s0.cuda_stream)
+    t0 = time.perf_counter()
+    for k in range(5, 5 + iters):
+        run(k)
+        s0.synchronize()
+    t = (time.perf_counter() - t0) / iters
+    fb.close()
+    return {"workload": "single filter, %d features (n=%d)" % (nf, 9 + 3 * nf), "latency_us_per_update": t * 1e6}
+
+
+def large_map(torch, dev, nf=2000, iters=2):
+    """configs[3] on one GPU: one filter with 2000 features (n = 6009, m = 10001)."""
+    from slam_amd import ekf
+    st, steps = build_inputs(torch, dev, 1, nf, iters + 1, 0)
+    fb = ekf.FilterBatch(max_features=nf, batch=1, device=dev.index or 0)
+    fb.set_state(0, X=st.init_pos)
+    fb.frame(0, first_frame(st), st.steps[0].quat)
+    n, m = 9 + 3 * nf, fb.num_rows(0)
+    s0 = torch.cuda.Stream(device=dev)
+    def run(k):
+        s = steps[k]
+        fb.frame_begin_dev(s0.cuda_stream)
+        fb.predict_dev(s["qbw"].data_ptr(), s["w"].data_ptr(), s["acc"].data_ptr(), s["dt"].data_ptr(), s0.cuda_stream)
+        fb.update_dev(s["qbw"].data_ptr(), None, s["src"].data_ptr(), s["refl"].data_ptr(), None, s0.cuda_stream)
+    run(0)
+    fb.sync(s0.cuda_stream)
+    fb.profile_enable(True)
+    t0 = time.perf_counter()
+    for k in range(1, 1 + iters):
+        run(k)
+    fb.sync(s0.cuda_stream)
+    t = (time.perf_counter() - t0) / iters
+    prof = fb.profile_read()
+    gemm_ms = sum(prof[k][0] for k in prof if k.startswith("gemm")) / iters
+    flops = ekf.flops_predict(n) + ekf.flops_update(n, m, 0)
+    P = fb.get_cov(0)
+    ok = bool(np.all(np.isfinite(P)) and np.abs(P - P.T).max() == 0 and np.all(np.diag(P) > 0))
+    fb.close()
+    return {"workload": "single filter, %d features (n=%d, m=%d)" % (nf, n, m), "updates_per_s": 1.0 / t,
+            "ms_per_update": t * 1e3, "gemm_tflops": flops / (gemm_ms * 1e-3) / 1e12,
+            "frac_of_fp64_matrix_peak": flops / (gemm_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
+            "stages_ms": {k: round(v[0] / iters, 3) for k, v in prof.items()}, "cov_sane": ok}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-per-gpu", type=int, default=4096)
+    ap.add_argument("--nf", type=int, default=32)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the single-filter and large-map side measurements")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from slam_amd import ekf
+    B, nf, K, W = args.batch_per_gpu, args.nf, args.steps, args.warmup
+    st, steps = build_inputs(torch, dev, B, nf, W + K, rank)
+    fb = ekf.FilterBatch(max_features=nf, batch=B, device=local)
+    for b in range(B):
+        fb.set_state(b, X=st.init_pos)
+    fb.frame(-1, first_frame(st), st.steps[0].quat)
+    n, m = 9 + 3 * nf, fb.num_rows(0)
+    stream = torch.cuda.Stream(device=dev)
+    applied = torch.zeros(B, dtype=torch.int32, device=dev)
+
+    def run(k):
+        s = steps[k]
+        fb.frame_begin_dev(stream.cuda_stream)
+        fb.predict_dev(s["qbw"].data_ptr(), s["w"].data_ptr(), s["acc"].data_ptr(), s["dt"].data_ptr(),
+                       stream.cuda_stream)
+        fb.update_dev(s["qbw"].data_ptr(), None, s["src"].data_ptr(), s["refl"].data_ptr(), applied.data_ptr(),
+                      stream.cuda_stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for k in range(W):
+        run(k)
+    fb.sync(stream.cuda_stream)
+    fb.profile_enable(True)
+    fb.profile_read()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(W, W + K):
+        run(k)
+    stream.synchronize()
+    barrier()
+    t = time.perf_counter() - t0
+    prof = fb.profile_read()
+    fb.profile_enable(False)
+    fb.sync(stream.cuda_stream)          # also raises on a per-filter status word
+    if dist is not None:
+        tt = torch.tensor([t], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = float(tt.item())
+
+    # sanity on the product of the timed region (never timed): finite, symmetric, positive diagonal
+    P = fb.get_cov(B // 2)
+    sane = bool(np.all(np.isfinite(P)) and np.array_equal(P, P.T) and np.all(np.diag(P) > 0)
+                and int(applied.sum().item()) == B)
+
+    if rank == 0:
+        gemm_ms = sum(v[0] for k, v in prof.items() if k.startswith("gemm"))
+        gemm_launch_groups = sum(v[1] for k, v in prof.items() if k.startswith("gemm"))
+        flops_step = B * (ekf.flops_predict(n) + ekf.flops_update(n, m, 0))
+        achieved = flops_step * K / (gemm_ms * 1e-3) / 1e12
+        traffic = None
+        side = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(side):
+            try:
+                traffic = json.load(open(side)).get("gemm_hbm_bytes_per_step")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "EKF updates/sec (state dim, batch) + fp64 MFMA % of peak, 1/2/4/8 GPUs",
+            "value": world * B * K / t, "unit": "EKF updates/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": t / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "batched Monte Carlo: %d independent filters x %d features per GPU "
+                                   "(state dim n=%d, measurement dim m=%d), one step = predict + image update of "
+                                   "every filter" % (B, nf, n, m),
+                       "batch_per_gpu": B, "features": nf, "state_dim": n, "meas_dim": m,
+                       "update_form": "cholesky gain + joseph covariance", "parallelism": "filters sharded x%d" % world},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "gemm_f64_kernel (all instantiations; %d launch groups timed with HIP events on the "
+                                   "launch stream)" % gemm_launch_groups,
+                         "flops_per_step": flops_step, "gemm_ms_per_step": gemm_ms / K},
+            "stages_ms_per_step": {k: round(v[0] / K, 4) for k, v in prof.items()},
+            "outputs_sane": sane,
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(st, steps, nf, W, W + K)
+        fb.close()
+        del steps
+        torch.cuda.empty_cache()
+        if world == 1 and not args.no_extra:
+            out["also"] = {"single_filter": single_filter_latency(torch, dev), "large_map": large_map(torch, dev)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -146,8 +146,18 @@ int slamk_dgemm_dev(int trans_b, int M, int N, int K, double alpha, const double
 /* Issue-rate probe: runs `iters` dependent-free v_mfma_f64_16x16x4_f64 per wave on every CU and
  * returns the achieved TFLOP/s in *tflops. */
 int slamk_mfma_f64_probe(int iters, double* tflops);
-/* FLOPs the covariance kernels execute for one predict / one update of a filter with the given
- * padded dimensions (what roofline fractions are computed from). */
+/* Stage timing with HIP events recorded on the launch stream around each group of kernels.
+ * Categories (index into ms/count, ncat >= 6): 0 per-feature and elementwise kernels,
+ * 1 GEMMs of the covariance predict, 2 GEMMs of the gain (W, S, Y, K), 3 GEMMs of the covariance
+ * update, 4 GEMMs inside the Cholesky factorisation / triangular inverse, 5 diagonal-block
+ * factorisation kernel.  slamk_profile_read synchronises, returns the accumulated milliseconds
+ * and scope counts since the previous read, and resets them. */
+int slamk_profile_enable(slamk_handle* h, int on);
+int slamk_profile_read(slamk_handle* h, double* ms, int* count, int ncat);
+/* FLOPs the MFMA GEMM launches execute for one predict / one update of a filter of state dimension n
+ * and measurement dimension m (tile skipping and triangular k-range trimming included; the small
+ * diagonal-block factorisations and the K e product, which do not run on MFMA, excluded).  This is
+ * the numerator of the fp64-matrix roofline fraction. */
 double slamk_flops_predict(int n);
 double slamk_flops_update(int n, int m, int update_form);
 

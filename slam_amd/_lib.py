@@ -52,6 +52,8 @@ SIGNATURES = {
     "slamk_dgemm_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int, C.c_longlong,
                                   _vp, C.c_int, C.c_longlong, C.c_double, _vp, C.c_int, C.c_longlong, C.c_int, _vp]),
     "slamk_mfma_f64_probe": (C.c_int, [C.c_int, _dp]),
+    "slamk_profile_enable": (C.c_int, [_H, C.c_int]),
+    "slamk_profile_read": (C.c_int, [_H, _dp, C.POINTER(C.c_int), C.c_int]),
     "slamk_flops_predict": (C.c_double, [C.c_int]),
     "slamk_flops_update": (C.c_double, [C.c_int, C.c_int, C.c_int]),
 }

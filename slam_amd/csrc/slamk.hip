@@ -56,6 +56,11 @@ struct slamk_handle {
     std::string err;
     hipStream_t stream = nullptr;
     int last_nl = 0, last_ml = 0;
+    // optional per-stage timing with HIP events on the launch stream (slamk_profile_*)
+    bool prof_on = false;
+    struct ProfRec { int cat; hipEvent_t a, b; };
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
 };
 
 namespace {
@@ -76,6 +81,34 @@ int fail(slamk_handle* h, int code, const char* fmt, ...)
         hipError_t e_ = (call);                                                                    \
         if (e_ != hipSuccess) return fail(h, SLAMK_EHIP, "%s: %s", #call, hipGetErrorString(e_));  \
     } while (0)
+
+// Stage categories reported by slamk_profile_read.
+enum ProfCat {
+    PC_FEATURE = 0,      // per-feature and elementwise kernels
+    PC_GEMM_PREDICT = 1, // P F^T, F T + Q
+    PC_GEMM_GAIN = 2,    // W, S, Y, K
+    PC_GEMM_COV = 3,     // I - K H, A P, (A P) A^T, (K R) K^T
+    PC_GEMM_CHOL = 4,    // panel / trailing / inverse products of the factorisation
+    PC_POTF2 = 5,        // diagonal-block factor + inverse
+    PC_COUNT = 6
+};
+
+struct ProfScope {
+    slamk_handle* h; hipStream_t st; hipEvent_t b = nullptr;
+    ProfScope(slamk_handle* h_, int cat, hipStream_t st_) : h(h_), st(st_)
+    {
+        if (!h->prof_on) return;
+        hipEvent_t ev[2];
+        for (auto& e : ev) {
+            if (!h->prof_pool.empty()) { e = h->prof_pool.back(); h->prof_pool.pop_back(); }
+            else (void)hipEventCreate(&e);
+        }
+        (void)hipEventRecord(ev[0], st);
+        b = ev[1];
+        h->prof_recs.push_back({cat, ev[0], ev[1]});
+    }
+    ~ProfScope() { if (b) (void)hipEventRecord(b, st); }
+};
 
 template <typename T>
 int dalloc(slamk_handle* h, T** p, size_t count)
@@ -167,9 +200,13 @@ int run_predict(slamk_handle* h, const double* qbw, const double* w, const doubl
     const int B = h->B, nl = max_nl(h), ldn = h->ldn;
     const long long sN = (long long)ldn * ldn;
     h->last_nl = nl;
-    hipLaunchKernelGGL(build_F_kernel, dim3((nl + 63) / 64, (nl + 3) / 4, B), dim3(256), 0, st, h->fv, qbw, w, dt,
-                       h->Fm, nl);
-    hipLaunchKernelGGL(dynamics_kernel, dim3(B), dim3(256), 0, st, h->fv, qbw, w, acc, dt);
+    {
+        ProfScope ps(h, PC_FEATURE, st);
+        hipLaunchKernelGGL(build_F_kernel, dim3((nl + 63) / 64, (nl + 3) / 4, B), dim3(256), 0, st, h->fv, qbw, w,
+                           dt, h->Fm, nl);
+        hipLaunchKernelGGL(dynamics_kernel, dim3(B), dim3(256), 0, st, h->fv, qbw, w, acc, dt);
+    }
+    ProfScope ps(h, PC_GEMM_PREDICT, st);
     // T = P F^T ; P = F T + Q      (calcP, src/slam/main.cpp:526-530, G = I)
     HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_NONE>(
                   gargs(h->fv.P, ldn, sN, h->Fm, ldn, sN, h->T, ldn, sN, nl, nl, nl), B, st)));
@@ -187,14 +224,18 @@ int run_cholesky_inverse(slamk_handle* h, int ml, hipStream_t st)
     // blocked right-looking Cholesky of S (lower) into L, diagonal-block inverses into Li
     for (int j0 = 0; j0 < ml; j0 += NB) {
         const int nb = std::min(NB, ml - j0);
-        if (NB == 64)
-            hipLaunchKernelGGL(potf2_inv_kernel<64>, dim3(B), dim3(256), (64 * 65 + 64) * sizeof(double), st, h->S,
-                               h->L, h->Li, ldm, sM, j0, nb);
-        else
-            hipLaunchKernelGGL(potf2_inv_kernel<128>, dim3(B), dim3(256), (128 * 129 + 128) * sizeof(double), st,
-                               h->S, h->L, h->Li, ldm, sM, j0, nb);
+        {
+            ProfScope ps(h, PC_POTF2, st);
+            if (NB == 64)
+                hipLaunchKernelGGL(potf2_inv_kernel<64>, dim3(B), dim3(256), (64 * 65 + 64) * sizeof(double), st,
+                                   h->S, h->L, h->Li, ldm, sM, j0, nb);
+            else
+                hipLaunchKernelGGL(potf2_inv_kernel<128>, dim3(B), dim3(256), (128 * 129 + 128) * sizeof(double), st,
+                                   h->S, h->L, h->Li, ldm, sM, j0, nb);
+        }
         const int rem = ml - j0 - nb;
         if (rem <= 0) break;
+        ProfScope ps(h, PC_GEMM_CHOL, st);
         const long long o21 = (long long)(j0 + nb) * ldm + j0, o11 = (long long)j0 * ldm + j0;
         const long long o22 = (long long)(j0 + nb) * ldm + (j0 + nb);
         // L21 = S21 inv(L11)^T
@@ -208,6 +249,7 @@ int run_cholesky_inverse(slamk_handle* h, int ml, hipStream_t st)
     // inv(L) by recursive doubling on the block diagonal:
     //   inv([[A,0],[Bk,C]]) = [[inv A, 0], [-inv C * Bk * inv A, inv C]]
     // S's lower part is dead after the factorisation and holds the intermediate Bk * inv A.
+    ProfScope ps_inv(h, PC_GEMM_CHOL, st);
     for (int s = NB; s < ml; s *= 2) {
         const int nfull = ml / (2 * s), r = ml - nfull * 2 * s;
         for (int pass = 0; pass < 2; ++pass) {
@@ -243,9 +285,15 @@ int run_update(slamk_handle* h, const double* qbw, const double* alt, const doub
     if (!src) src = h->fv.msrc;
     if (!refl) refl = h->fv.mrefl;
 
-    hipLaunchKernelGGL(measure_kernel, dim3(std::max(1, (nfmax + 63) / 64), B), dim3(64), 0, st, h->fv, qbw, alt, src,
-                       refl, ml);
-    hipLaunchKernelGGL(build_H_kernel, dim3((nl + 63) / 64, (ml + 3) / 4, B), dim3(256), 0, st, h->fv, h->Hm, ml, nl);
+    {
+        ProfScope ps(h, PC_FEATURE, st);
+        hipLaunchKernelGGL(measure_kernel, dim3(std::max(1, (nfmax + 63) / 64), B), dim3(64), 0, st, h->fv, qbw, alt,
+                           src, refl, ml);
+        hipLaunchKernelGGL(build_H_kernel, dim3((nl + 63) / 64, (ml + 3) / 4, B), dim3(256), 0, st, h->fv, h->Hm, ml,
+                           nl);
+    }
+    {
+    ProfScope ps(h, PC_GEMM_GAIN, st);
     // W = P H^T                                  (calcK, src/slam/main.cpp:545)
     HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_NONE>(
                   gargs(h->fv.P, ldn, sN, h->Hm, ldn, sMN, h->W, ldm, sNM, nl, ml, nl), B, st)));
@@ -253,9 +301,12 @@ int run_update(slamk_handle* h, const double* qbw, const double* alt, const doub
     HIPCHK(h, (launch_gemm<false, EPI_DIAG_ADD, true, TRI_NONE>(
                   gargs(h->Hm, ldn, sMN, h->W, ldm, sNM, h->S, ldm, sM, ml, ml, nl, 1.0, 0.0, h->fv.rdiag, ldm), B,
                   st)));
+    }
     // S = L L^T, Li = inv(L)
     int rc = run_cholesky_inverse(h, ml, st);
     if (rc) return rc;
+    {
+    ProfScope ps(h, PC_GEMM_GAIN, st);
     // K = W S^-1 = (W Li^T) Li                   (:547-550 solved by Cholesky instead of LU)
     HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_B_KLE_N>(
                   gargs(h->W, ldm, sNM, h->Li, ldm, sM, h->Y, ldm, sNM, nl, ml, ml), B, st)));
@@ -265,13 +316,16 @@ int run_update(slamk_handle* h, const double* qbw, const double* alt, const doub
         g.C2 = h->KR;
         HIPCHK(h, (launch_gemm<false, EPI_DUAL_COLSCALE, false, TRI_B_KGE_N>(g, B, st)));
     }
+    }
+    const double* presym = h->AP;
+    {
+    ProfScope ps(h, PC_GEMM_COV, st);
     // A = I - K H                                (updateP, :563-565)
     HIPCHK(h, (launch_gemm<false, EPI_EYE_MINUS, false, TRI_NONE>(
                   gargs(h->K, ldm, sNM, h->Hm, ldn, sMN, h->Am, ldn, sN, nl, nl, ml), B, st)));
     // AP = A P
     HIPCHK(h, (launch_gemm<false, EPI_NONE, false, TRI_NONE>(
                   gargs(h->Am, ldn, sN, h->fv.P, ldn, sN, h->AP, ldn, sN, nl, nl, nl), B, st)));
-    const double* presym = h->AP;
     if (h->prm.update_form == 0) {
         // Joseph: P = AP A^T + (K R) K^T
         HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_NONE>(
@@ -280,6 +334,8 @@ int run_update(slamk_handle* h, const double* qbw, const double* alt, const doub
                       gargs(h->KR, ldm, sNM, h->K, ldm, sNM, h->T, ldn, sN, nl, nl, ml, 1.0, 1.0), B, st)));
         presym = h->T;
     }
+    }
+    ProfScope ps(h, PC_FEATURE, st);
     // P = (P + P^T)/2                            (:567)
     hipLaunchKernelGGL(symmetrize_kernel, dim3((nl + 31) / 32, (nl + 31) / 32, B), dim3(256), 0, st, presym, h->fv.P,
                        ldn, sN, nl);
@@ -752,6 +808,31 @@ int slamk_mfma_f64_probe(int iters, double* tflops)
     return SLAMK_OK;
 }
 
+int slamk_profile_enable(slamk_handle* h, int on)
+{
+    if (!h) return SLAMK_EINVAL;
+    h->prof_on = on != 0;
+    return SLAMK_OK;
+}
+
+int slamk_profile_read(slamk_handle* h, double* ms, int* count, int ncat)
+{
+    if (!h || !ms || !count || ncat < PC_COUNT) return SLAMK_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    for (int i = 0; i < ncat; ++i) { ms[i] = 0; count[i] = 0; }
+    for (auto& r : h->prof_recs) {
+        float t = 0;
+        HIPCHK(h, hipEventElapsedTime(&t, r.a, r.b));
+        ms[r.cat] += t;
+        count[r.cat] += 1;
+        h->prof_pool.push_back(r.a);
+        h->prof_pool.push_back(r.b);
+    }
+    h->prof_recs.clear();
+    return SLAMK_OK;
+}
+
 double slamk_flops_predict(int n)
 {
     const int nl = pad16(n);
@@ -767,8 +848,6 @@ double slamk_flops_update(int n, int m, int update_form)
     const int NB = (ml <= 1024) ? 64 : 128;
     for (int j0 = 0; j0 < ml; j0 += NB) {
         const int nb = std::min(NB, ml - j0), rem = ml - j0 - nb;
-        f += (double)nb * nb * nb / 3;                          // diagonal block factor
-        f += (double)nb * nb * nb / 3;                          // and its inverse
         if (rem <= 0) break;
         f += gemm_flops(rem, nb, nb, false, TRI_B_KLE_N);
         f += gemm_flops(rem, rem, nb, true, TRI_NONE);
@@ -786,7 +865,6 @@ double slamk_flops_update(int n, int m, int update_form)
         f += gemm_flops(nl, nl, nl, false, TRI_NONE);          // (A P) A^T
         f += gemm_flops(nl, nl, ml, false, TRI_NONE);          // (K R) K^T
     }
-    f += 2.0 * n * m;                                          // K e
     return f;
 }
 

@@ -160,6 +160,19 @@ class FilterBatch:
     def sync(self, stream=0):
         self._chk(self.L.slamk_sync(self.h, stream))
 
+    PROFILE_STAGES = ("feature_kernels", "gemm_predict", "gemm_gain", "gemm_cov_update", "gemm_cholesky", "potf2_inv")
+
+    def profile_enable(self, on=True):
+        self._chk(self.L.slamk_profile_enable(self.h, int(bool(on))))
+
+    def profile_read(self):
+        """{stage: (milliseconds, scopes)} accumulated since the last read (HIP events on the launch stream)."""
+        n = len(self.PROFILE_STAGES)
+        ms = (C.c_double * n)()
+        cnt = (C.c_int * n)()
+        self._chk(self.L.slamk_profile_read(self.h, ms, cnt, n))
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(self.PROFILE_STAGES)}
+
     # ---- introspection -----------------------------------------------------------------------
     def debug_get(self, b):
         n, m = 9 + 3 * self.num_features(b), self.num_rows(b)
