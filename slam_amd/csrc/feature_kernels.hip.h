@@ -335,33 +335,40 @@ __global__ void __launch_bounds__(256) build_H_kernel(FilterView fv, double* __r
     Hm[(long long)b * fv.ldm * fv.ldn + (long long)q * fv.ldn + k] = v;
 }
 
-// dx = K e, gate, mean update (src/slam/main.cpp:228-232; States(const Mat&) states.cpp:24-37:
-// bias rows of dx are ignored).  One workgroup per filter; a wavefront reduces one row of K.
-__global__ void __launch_bounds__(256) gain_apply_kernel(FilterView fv, const double* __restrict__ K,
-                                                          double* __restrict__ dx, int* __restrict__ applied, int ml)
+// dx = K e (src/slam/main.cpp:228): one wavefront per row of K, 16 rows per workgroup.
+// Bias rows are skipped (States(const Mat&), src/ARC/states.cpp:24-37, ignores them).
+__global__ void __launch_bounds__(256) gain_kx_kernel(FilterView fv, const double* __restrict__ K,
+                                                       double* __restrict__ dx, int ml)
 {
-    const int b = blockIdx.x;
-    const int nf = fv.nf[b], n = 9 + 3 * nf;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int b = blockIdx.y;
+    const int n = 9 + 3 * fv.nf[b];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double* Kb = K + (long long)b * fv.ldn * fv.ldm;
     const double* e = fv.e + (long long)b * fv.ldm;
     double* d = dx + (long long)b * fv.ldn;
-    for (int r = wave; r < n - 3; r += nw) {
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = blockIdx.x * 16 + wave * 4 + rr;
+        if (r >= n - 3) return;
         double s = 0.0;
         for (int q = lane; q < ml; q += 64) s += Kb[(long long)r * fv.ldm + q] * e[q];
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (lane == 0) d[r] = s;
     }
-    __syncthreads();
-    __shared__ int ok_s;
-    if (threadIdx.x == 0) {
-        const double* V = fv.V + 3 * b;
-        const double g = fabs(V[0] - d[3]) + fabs(V[1] - d[4]) + fabs(V[2] - d[5]);
-        ok_s = g < fv.gate;
-        if (applied) applied[b] = ok_s;
-    }
-    __syncthreads();
-    if (!ok_s) return;
+}
+
+// Gate and mean update (src/slam/main.cpp:229-232): `if (sum|V - dV| < gate) mu += dx` on X, V, pib.
+__global__ void __launch_bounds__(256) gain_apply_kernel(FilterView fv, const double* __restrict__ dx,
+                                                          int* __restrict__ applied)
+{
+    const int b = blockIdx.x;
+    const int nf = fv.nf[b];
+    const double* d = dx + (long long)b * fv.ldn;
+    const double* V = fv.V + 3 * b;
+    const double g = fabs(V[0] - d[3]) + fabs(V[1] - d[4]) + fabs(V[2] - d[5]);
+    const bool ok = g < fv.gate;
+    __syncthreads();                       // every thread has read V before anyone updates it
+    if (threadIdx.x == 0 && applied) applied[b] = ok;
+    if (!ok) return;
     if (threadIdx.x < 3) {
         fv.X[3 * b + threadIdx.x] += d[threadIdx.x];
         fv.V[3 * b + threadIdx.x] += d[3 + threadIdx.x];

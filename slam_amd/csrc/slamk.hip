@@ -227,10 +227,10 @@ int run_cholesky_inverse(slamk_handle* h, int ml, hipStream_t st)
         {
             ProfScope ps(h, PC_POTF2, st);
             if (NB == 64)
-                hipLaunchKernelGGL(potf2_inv_kernel<64>, dim3(B), dim3(256), (64 * 65 + 64) * sizeof(double), st,
+                hipLaunchKernelGGL(potf2_inv_kernel<64>, dim3(B), dim3(256), (64 * 65 + 4 * 16 * 17) * sizeof(double), st,
                                    h->S, h->L, h->Li, ldm, sM, j0, nb);
             else
-                hipLaunchKernelGGL(potf2_inv_kernel<128>, dim3(B), dim3(256), (128 * 129 + 128) * sizeof(double), st,
+                hipLaunchKernelGGL(potf2_inv_kernel<128>, dim3(B), dim3(256), (128 * 129 + 8 * 16 * 17) * sizeof(double), st,
                                    h->S, h->L, h->Li, ldm, sM, j0, nb);
         }
         const int rem = ml - j0 - nb;
@@ -340,7 +340,8 @@ int run_update(slamk_handle* h, const double* qbw, const double* alt, const doub
     hipLaunchKernelGGL(symmetrize_kernel, dim3((nl + 31) / 32, (nl + 31) / 32, B), dim3(256), 0, st, presym, h->fv.P,
                        ldn, sN, nl);
     // dx = K e, gate, mean update                (main.cpp:228-232)
-    hipLaunchKernelGGL(gain_apply_kernel, dim3(B), dim3(256), 0, st, h->fv, h->K, h->dx, applied, ml);
+    hipLaunchKernelGGL(gain_kx_kernel, dim3((nl + 15) / 16, B), dim3(256), 0, st, h->fv, h->K, h->dx, ml);
+    hipLaunchKernelGGL(gain_apply_kernel, dim3(B), dim3(256), 0, st, h->fv, h->dx, applied);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -421,7 +422,7 @@ int slamk_create(const slamk_params* p, int max_features, int batch, int device,
     v.inv_dmax = 1 / h->prm.d_max; v.inv_dmin = 1 / h->prm.d_min;
     v.alt_override = h->prm.alt_override; v.use_alt_override = h->prm.use_alt_override;
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_kernel<128>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (128 * 129 + 128) * sizeof(double)));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (128 * 129 + 8 * 16 * 17) * sizeof(double)));
     hipLaunchKernelGGL(init_cov_kernel, dim3(batch), dim3(64), 0, 0, v.P, h->ldn, (long long)ldn * ldn, h->prm.pinit);
     for (int b = 0; b < batch; ++b) {
         int one = 1;
