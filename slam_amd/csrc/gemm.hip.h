@@ -6,11 +6,12 @@
 // One 256-thread workgroup (4 waves as 2 x 2) owns a BM x BN tile of C; each wave owns a
 // (BM/2) x (BN/2) sub-tile as TM x TN accumulators of 16 x 16.  K is walked in slabs of 16:
 // the next slab is fetched from global memory into registers while the MFMAs of the current
-// slab run out of LDS (register-staged software pipeline, one LDS buffer).
+// slab run out of LDS (register-staged software pipeline over two LDS buffers, one barrier per slab).
 //
-// LDS images are laid out so that the 64-bit operand reads are bank-conflict free:
-//   k-contiguous operands (A, and B when TB) : [row][18]  -> lane (i = l&15, kk = l>>4) reads
-//       dword 36 i + 2 kk (+8 s): the 32 lanes of a half-wave hit 32 distinct even banks.
+// LDS images are laid out so that the operand reads are bank-conflict free:
+//   k-contiguous operands (A, and B when TB) : [row][20]  -> lane (i = l&15, kk = l>>4) reads the
+//       16 bytes at dword 40 i + 4 kk (+16 t) with ds_read_b128; each of that instruction's four
+//       16-lane groups covers all 64 banks exactly once, and the staging ds_write_b128 is clean too.
 //   n-contiguous operand (B when !TB)        : [k][BN+16] -> row stride 2(BN+16) dwords == 32 mod 64,
 //       so the two k rows a half-wave touches land in opposite halves of the 64 banks.
 //
@@ -55,11 +56,14 @@ struct GemmArgs {
 template <int BM, int BN, bool TB, int EPI, bool LOWER, int TRI>
 __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmArgs g)
 {
-    constexpr int LDS_K = 18;                       // row stride of k-contiguous images (doubles)
+    constexpr int LDS_K = 20;                       // row stride of k-contiguous images (doubles)
     constexpr int LDS_N = BN + 16;                  // row stride of the n-contiguous B image
     constexpr int TM = BM / 32, TN = BN / 32;
-    __shared__ double As[BM * LDS_K];
-    __shared__ double Bs[TB ? BN * LDS_K : 16 * LDS_N];
+    constexpr int NBUF = (BM >= 128) ? 2 : 1;       // big tiles: two slabs in flight, one barrier per slab
+    constexpr int A_SZ = BM * LDS_K;
+    constexpr int B_SZ = TB ? BN * LDS_K : 16 * LDS_N;
+    __shared__ __attribute__((aligned(16))) double As[NBUF * A_SZ];
+    __shared__ __attribute__((aligned(16))) double Bs[NBUF * B_SZ];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -113,43 +117,82 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmArgs g)
             }
         }
     };
-    auto stash = [&]() {
+    auto stash = [&](int buf) {
+        double* Ad = As + buf * A_SZ;
+        double* Bd = Bs + buf * B_SZ;
 #pragma unroll
         for (int r = 0; r < TM; ++r)
-            *reinterpret_cast<double2*>(&As[(arow + 32 * r) * LDS_K + akp]) = ra[r];
+            *reinterpret_cast<double2*>(&Ad[(arow + 32 * r) * LDS_K + akp]) = ra[r];
         if (TB) {
 #pragma unroll
             for (int r = 0; r < TN; ++r)
-                *reinterpret_cast<double2*>(&Bs[(arow + 32 * r) * LDS_K + akp]) = rb[r];
+                *reinterpret_cast<double2*>(&Bd[(arow + 32 * r) * LDS_K + akp]) = rb[r];
         } else {
 #pragma unroll
             for (int r = 0; r < TN; ++r)
-                *reinterpret_cast<double2*>(&Bs[(brow + (256 / BLPR) * r) * LDS_N + bcol]) = rb[r];
+                *reinterpret_cast<double2*>(&Bd[(brow + (256 / BLPR) * r) * LDS_N + bcol]) = rb[r];
         }
     };
 
+    // Lane l = (li = l & 15, lk = l >> 4) feeds row/column li of a 16 x 16 tile.  Each MFMA sums over 4
+    // values of k, one per lk; WHICH 4 is free as long as A and B agree, so lane lk takes the adjacent
+    // pair k = 8 t + 2 lk + {0, 1}: one 16-byte LDS read serves two MFMAs.
     const int li = lane & 15, lk = lane >> 4;
-    const double* aBase = &As[(wr * (BM / 2) + li) * LDS_K + lk];
-    const double* bBase = TB ? &Bs[(wc * (BN / 2) + li) * LDS_K + lk] : &Bs[lk * LDS_N + wc * (BN / 2) + li];
+    const double* aBase = &As[(wr * (BM / 2) + li) * LDS_K + 2 * lk];
+    const double* bBase = TB ? &Bs[(wc * (BN / 2) + li) * LDS_K + 2 * lk] : &Bs[2 * lk * LDS_N + wc * (BN / 2) + li];
 
-    if (kb < ke) fetch(kb);
-    for (int k0 = kb; k0 < ke; k0 += 16) {
-        __syncthreads();                 // every wave is done reading the previous slab
-        stash();
-        __syncthreads();
-        if (k0 + 16 < ke) fetch(k0 + 16);
+    auto compute = [&](int buf) {
+        const double* aB = aBase + buf * A_SZ;
+        const double* bB = bBase + buf * B_SZ;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            double a[TM], b[TN];
+        for (int t = 0; t < 2; ++t) {
+            double2 a2[TM], b2[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = aBase[i * 16 * LDS_K + 4 * s];
+            for (int i = 0; i < TM; ++i) a2[i] = *reinterpret_cast<const double2*>(&aB[i * 16 * LDS_K + 8 * t]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = TB ? bBase[j * 16 * LDS_K + 4 * s] : bBase[4 * s * LDS_N + j * 16];
+            for (int j = 0; j < TN; ++j) {
+                if (TB) b2[j] = *reinterpret_cast<const double2*>(&bB[j * 16 * LDS_K + 8 * t]);
+                else b2[j] = make_double2(bB[(8 * t) * LDS_N + j * 16], bB[(8 * t + 1) * LDS_N + j * 16]);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[i].x, b2[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[i].y, b2[j].y, acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (NBUF == 2) {
+        // one barrier per slab: while the MFMAs of slab k run out of buffer k&1, slab k+1 (already in
+        // registers) is written to the other buffer and slab k+2 is requested from global memory
+        if (kb < ke) {
+            fetch(kb);
+            stash(0);
+            if (kb + 16 < ke) fetch(kb + 16);
+        }
+        __syncthreads();
+        int buf = 0;
+        for (int k0 = kb; k0 < ke; k0 += 16, buf ^= 1) {
+            if (k0 + 16 < ke) {
+                stash(buf ^ 1);
+                if (k0 + 32 < ke) fetch(k0 + 32);
+            }
+            compute(buf);
+            __syncthreads();
+        }
+    } else {
+        if (kb < ke) fetch(kb);
+        for (int k0 = kb; k0 < ke; k0 += 16) {
+            __syncthreads();             // every wave is done reading the previous slab
+            stash(0);
+            __syncthreads();
+            if (k0 + 16 < ke) fetch(k0 + 16);
+            compute(0);
         }
     }
 
