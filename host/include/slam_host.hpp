@@ -1,0 +1,242 @@
+// Host-side mirror of the reference's types for the estimator's text front end.
+//
+// The reference's headers (include/Quaternion.hpp, Sensor.hpp, Sensors.hpp, featureIO.h,
+// imagesensor.hpp, states.h) embed OpenCV value types; this header keeps their public shape
+// (class and member names, argument meaning, error behaviour) on small value types of its own, and
+// `States` forwards the numerical work to the C ABI (include/slamk.h) instead of cv::Mat code.
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/slamk.h"
+
+namespace slamhost {
+
+struct Vec3d {
+    double v[3] = {0, 0, 0};
+    Vec3d() {}
+    Vec3d(double a, double b, double c) { v[0] = a; v[1] = b; v[2] = c; }
+    double& operator[](int i) { return v[i]; }
+    const double& operator[](int i) const { return v[i]; }
+};
+struct Vec4d {
+    double v[4] = {0, 0, 0, 0};
+    double& operator[](int i) { return v[i]; }
+    const double& operator[](int i) const { return v[i]; }
+};
+struct Point2d {
+    double x = 0, y = 0;
+    Point2d() {}
+    Point2d(double a, double b) : x(a), y(b) {}
+    bool operator!=(const Point2d& o) const { return x != o.x || y != o.y; }
+};
+struct Matx33d {
+    double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double& operator()(int i, int j) { return m[3 * i + j]; }
+    double operator()(int i, int j) const { return m[3 * i + j]; }
+    Matx33d t() const
+    {
+        Matx33d r;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) r(i, j) = (*this)(j, i);
+        return r;
+    }
+    Vec3d operator*(const Vec3d& a) const
+    {
+        Vec3d r;
+        for (int i = 0; i < 3; ++i) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += m[3 * i + k] * a[k];
+            r[i] = s;
+        }
+        return r;
+    }
+};
+
+// include/Quaternion.hpp:11-39, src/ARC/Quaternion.cpp:32-47 (scalar last, not normalised)
+class Quaternion {
+   public:
+    Quaternion() {}
+    Quaternion(double q1, double q2, double q3, double q4) { coord[0] = q1; coord[1] = q2; coord[2] = q3; coord[3] = q4; }
+    Matx33d rotation() const
+    {
+        Matx33d m;
+        const double* c = coord.v;
+        m(0, 0) = pow(c[3], 2) + pow(c[0], 2) - pow(c[1], 2) - pow(c[2], 2);
+        m(1, 0) = 2 * (c[0] * c[1] + c[3] * c[2]);
+        m(2, 0) = 2 * (c[0] * c[2] - c[3] * c[1]);
+        m(0, 1) = 2 * (c[0] * c[1] - c[3] * c[2]);
+        m(1, 1) = pow(c[3], 2) - pow(c[0], 2) + pow(c[1], 2) - pow(c[2], 2);
+        m(2, 1) = 2 * (c[3] * c[0] + c[1] * c[2]);
+        m(0, 2) = 2 * (c[3] * c[1] + c[0] * c[2]);
+        m(1, 2) = 2 * (c[1] * c[2] - c[3] * c[0]);
+        m(2, 2) = pow(c[3], 2) - pow(c[0], 2) - pow(c[1], 2) + pow(c[2], 2);
+        return m;
+    }
+    Vec4d coord;
+};
+
+// include/Sensor.hpp:28-68
+template <class T>
+class Sensor {
+   public:
+    Sensor() : value(), timestamp(0), dt(0) {}
+    double get_timestamp() const { return timestamp; }
+    double get_dt() const { return dt; }
+    T get_value() const { return value; }
+    void set_value(double ts, T v)
+    {
+        dt = (timestamp == 0) ? 0 : ts - timestamp;
+        timestamp = ts;
+        value = v;
+    }
+    void set_value(T v) { value = v; }
+
+   private:
+    T value;
+    double timestamp;
+    double dt;
+};
+
+// include/Sensors.hpp:8-62, src/ARC/Sensors.cpp:4-70
+enum {
+    UPDATE_ACC = 1, UPDATE_ANG = 1 << 1, UPDATE_QUAT = 1 << 2, UPDATE_IMG = 1 << 3,
+    UPDATE_ALT = 1 << 4, UPDATE_INIT = 1 << 5, UPDATE_POS = 1 << 6, UPDATE_VEL = 1 << 7
+};
+
+class Sensors {
+   public:
+    Sensors() : t(0), time(-1), rv(0) { type[0] = vals[0] = 0; }
+    // Reads the lines of one time step (stamps closer than 5 ms to the first line) from stdin and
+    // returns the update bitmask, or -1 for the group that ends at end of input.
+    int update()
+    {
+        int updated = 0;
+        if (time == -1) rv = scanf("%lf,%31[^,\n],%255s", &time, type, vals);
+        t = time;
+        while (time - t < 0.005) {
+            if (rv == EOF) return -1;
+            Vec3d v3;
+            if (!strcmp(type, "ACC")) { updated |= UPDATE_ACC; sscanf(vals, "%lf,%lf,%lf", &v3[0], &v3[1], &v3[2]); acc.set_value(time, v3); }
+            else if (!strcmp(type, "ANG")) { updated |= UPDATE_ANG; sscanf(vals, "%lf,%lf,%lf", &v3[0], &v3[1], &v3[2]); ang.set_value(time, v3); }
+            else if (!strcmp(type, "IMG")) { updated |= UPDATE_IMG; img.set_value(time, 0); }
+            else if (!strcmp(type, "QUAT")) {
+                updated |= UPDATE_QUAT;
+                Quaternion q;
+                sscanf(vals, "%lf,%lf,%lf,%lf", &q.coord[0], &q.coord[1], &q.coord[2], &q.coord[3]);
+                quat.set_value(time, q);
+            }
+            else if (!strcmp(type, "ALT")) { updated |= UPDATE_ALT; double a = 0; sscanf(vals, "%lf", &a); alt.set_value(time, a); }
+            else if (!strcmp(type, "POS")) { updated |= UPDATE_POS; sscanf(vals, "%lf,%lf,%lf", &v3[0], &v3[1], &v3[2]); pos.set_value(time, v3); }
+            else if (!strcmp(type, "VEL")) { updated |= UPDATE_VEL; sscanf(vals, "%lf,%lf,%lf", &v3[0], &v3[1], &v3[2]); vel.set_value(time, v3); }
+            else if (!strcmp(type, "INIT")) { updated |= UPDATE_INIT; sscanf(vals, "%lf,%lf,%lf", &v3[0], &v3[1], &v3[2]); init.set_value(time, v3); }
+            rv = scanf("%lf,%31[^,\n],%255s", &time, type, vals);
+        }
+        return updated;
+    }
+    Sensor<Quaternion> quat;
+    Sensor<Vec3d> acc, ang, init, vel, pos;
+    Sensor<double> alt;
+    Sensor<int> img;
+
+   private:
+    double t, time;
+    int rv;
+    char type[32], vals[256];
+};
+
+// include/featureIO.h:31-37
+struct projection {
+    Point2d source, reflection;
+    int id = 0;
+    bool isRef() const { return reflection != Point2d(0, 0); }
+};
+
+// include/imagesensor.hpp:16-28, src/ARC/imagesensor.cpp:29-49, src/ARC/featureIO.cpp:52-59,104-128
+class ImageSensor {
+   public:
+    ImageSensor(const char* fn, bool /*isHex*/)
+    {
+        fp = fopen(fn, "r");
+        if (!fp) { perror("fopen body"); exit(EXIT_FAILURE); }
+    }
+    ~ImageSensor() { if (fp) fclose(fp); }
+    // one frame: lines `id,x,y,rx,ry` up to a blank line (-1) or end of file (-2)
+    int update()
+    {
+        matches.clear();
+        char line[1024];
+        for (;;) {
+            projection pj;
+            if (fgets(line, sizeof line, fp) == NULL) return -2;
+            int rv = sscanf(line, "%d,%lf,%lf,%lf,%lf", &pj.id, &pj.source.x, &pj.source.y, &pj.reflection.x, &pj.reflection.y);
+            if (rv < 0) return rv;
+            matches.push_back(pj);
+        }
+    }
+    std::vector<projection> matches;
+
+   private:
+    FILE* fp;
+};
+
+// include/states.h:21-59 -- the state lives on the GPU; this object is the handle plus the few
+// host-visible members main() touches.  Errors print the reference's message and exit(1).
+class States {
+   public:
+    explicit States(int max_features)
+    {
+        slamk_params p;
+        slamk_default_params(&p);
+        if (slamk_create(&p, max_features, 1, 0, &h) != SLAMK_OK) die("slamk_create");
+    }
+    ~States() { if (h) slamk_destroy(h); }
+    Vec3d X, V, b;
+    int getNumFeatures() const { return slamk_num_features(h, 0); }
+    int getRows() const { return 9 + 3 * getNumFeatures(); }
+    void pushX() { if (slamk_set_state(h, 0, X.v, nullptr, nullptr)) die("set_state"); }
+    void pushV() { if (slamk_set_state(h, 0, nullptr, V.v, nullptr)) die("set_state"); }
+    void pull() { if (slamk_get_state(h, 0, X.v, V.v, b.v)) die("get_state"); }
+    // States::update_features(imgsense, sense, P): association + covariance surgery on the device
+    void update_features(const ImageSensor& imgsense, const Sensors& sense)
+    {
+        std::vector<slamk_match> m(imgsense.matches.size());
+        for (size_t i = 0; i < m.size(); ++i) {
+            const projection& p = imgsense.matches[i];
+            m[i].id = p.id; m[i].sx = p.source.x; m[i].sy = p.source.y; m[i].rx = p.reflection.x; m[i].ry = p.reflection.y;
+        }
+        const Quaternion q = sense.quat.get_value();
+        int rc = slamk_frame(h, 0, m.data(), (int)m.size(), q.coord.v);
+        if (rc == SLAMK_ENOMATCH) { fprintf(stderr, "Cannot find match.\n"); exit(EXIT_FAILURE); }
+        if (rc) die("slamk_frame");
+    }
+    // F, mu += dynamics*dt, P = F P F^T + Q     (main.cpp:192-194,204-206)
+    void predict(const Sensors& sense, double dt)
+    {
+        const Quaternion q = sense.quat.get_value();
+        const Vec3d w = sense.ang.get_value(), a = sense.acc.get_value();
+        if (slamk_predict(h, q.coord.v, w.v, a.v, &dt)) die("slamk_predict");
+    }
+    // measurement model, gain, covariance and gated mean update     (main.cpp:198-202,209-233)
+    void update(const Sensors& sense)
+    {
+        const Quaternion q = sense.quat.get_value();
+        const double alt = sense.alt.get_value();
+        int applied = 0;
+        int rc = slamk_update(h, q.coord.v, &alt, &applied);
+        if (rc) die("slamk_update");
+    }
+    slamk_handle* h = nullptr;
+
+   private:
+    [[noreturn]] void die(const char* what)
+    {
+        fprintf(stderr, "%s: %s\n", what, h ? slamk_last_error(h) : "no handle");
+        exit(EXIT_FAILURE);
+    }
+};
+
+}  // namespace slamhost
