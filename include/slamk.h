@@ -132,6 +132,24 @@ int slamk_update_dev(slamk_handle* h, const double* qbw_dev, const double* alt_d
 /* Waits for `stream` and returns SLAMK_EREFL / SLAMK_OK from the per-filter status words. */
 int slamk_sync(slamk_handle* h, void* stream);
 
+/* ---- stage-level entry points: the pieces a row-block sharded large-map filter needs around its
+ * own distributed products (slam_amd/sharded.py).  Device pointers, asynchronous on `stream`. ----- */
+/* jacobianMotionModel (main.cpp:241-341) into the handle's dense F, initQ diagonal (:430-440) and
+ * mu += dynamics(mu) dt (states.cpp:222-263); no covariance product. */
+int slamk_stage_motion_dev(slamk_handle* h, const double* qbw_dev, const double* w_dev, const double* acc_dev,
+                           const double* dt_dev, void* stream);
+/* measurementModel / jacobianH / initR (main.cpp:348-408,449-476,575-624): innovation, diag R, dense H. */
+int slamk_stage_measure_dev(slamk_handle* h, const double* qbw_dev, const double* alt_dev, const double* src_dev,
+                            const double* refl_dev, void* stream);
+/* dx = K e with the caller's gain K (n x m, leading dimension ldk), gate and mean update (main.cpp:228-232). */
+int slamk_stage_apply_dev(slamk_handle* h, const double* K_dev, int ldk, int32_t* applied_dev, void* stream);
+/* Device address and shape of one of the handle's matrices (filter 0): which = 0 F, 1 H, 2 innovation e,
+ * 3 diag R, 4 diag Q, 5 P.  rows/cols are the padded live dimensions, ld the leading dimension. */
+int slamk_buffer_dev(slamk_handle* h, int which, double** ptr, int* rows, int* cols, int* ld);
+/* Cholesky of the lower triangle of S (m x m, m a multiple of 16) into L and inv(L) into Li (both
+ * lower; the strict upper triangles of L and Li must be zero on entry).  S is overwritten. */
+int slamk_cholesky_inverse_dev(double* S_dev, double* L_dev, double* Li_dev, int m, int ld, void* stream);
+
 /* ---- introspection for tests and benchmarks (no counterpart in the reference) ----------- */
 /* Copies of the last update's intermediates of filter b (NULL = skip): H m x n, S's Cholesky
  * factor L m x m (lower), K n x m, innovation e[m]. */

@@ -337,20 +337,20 @@ __global__ void __launch_bounds__(256) build_H_kernel(FilterView fv, double* __r
 
 // dx = K e (src/slam/main.cpp:228): one wavefront per row of K, 16 rows per workgroup.
 // Bias rows are skipped (States(const Mat&), src/ARC/states.cpp:24-37, ignores them).
-__global__ void __launch_bounds__(256) gain_kx_kernel(FilterView fv, const double* __restrict__ K,
+__global__ void __launch_bounds__(256) gain_kx_kernel(FilterView fv, const double* __restrict__ K, int ldk,
                                                        double* __restrict__ dx, int ml)
 {
     const int b = blockIdx.y;
     const int n = 9 + 3 * fv.nf[b];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const double* Kb = K + (long long)b * fv.ldn * fv.ldm;
+    const double* Kb = K + (long long)b * fv.ldn * ldk;
     const double* e = fv.e + (long long)b * fv.ldm;
     double* d = dx + (long long)b * fv.ldn;
     for (int rr = 0; rr < 4; ++rr) {
         const int r = blockIdx.x * 16 + wave * 4 + rr;
         if (r >= n - 3) return;
         double s = 0.0;
-        for (int q = lane; q < ml; q += 64) s += Kb[(long long)r * fv.ldm + q] * e[q];
+        for (int q = lane; q < ml; q += 64) s += Kb[(long long)r * ldk + q] * e[q];
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (lane == 0) d[r] = s;
     }

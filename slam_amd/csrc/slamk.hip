@@ -216,10 +216,10 @@ int run_predict(slamk_handle* h, const double* qbw, const double* w, const doubl
     return 0;
 }
 
-int run_cholesky_inverse(slamk_handle* h, int ml, hipStream_t st)
+// S (lower) -> L (Cholesky factor) and Li = inv(L); S is used as scratch afterwards.
+int cholesky_inverse(slamk_handle* h, double* Sp, double* Lp, double* Lip, int ldm, long long sM, int B, int ml,
+                     hipStream_t st)
 {
-    const int B = h->B, ldm = h->ldm;
-    const long long sM = (long long)ldm * ldm;
     const int NB = (ml <= 1024) ? 64 : 128;
     // blocked right-looking Cholesky of S (lower) into L, diagonal-block inverses into Li
     for (int j0 = 0; j0 < ml; j0 += NB) {
@@ -228,10 +228,10 @@ int run_cholesky_inverse(slamk_handle* h, int ml, hipStream_t st)
             ProfScope ps(h, PC_POTF2, st);
             if (NB == 64)
                 hipLaunchKernelGGL(potf2_inv_kernel<64>, dim3(B), dim3(256), (64 * 65 + 4 * 16 * 17) * sizeof(double), st,
-                                   h->S, h->L, h->Li, ldm, sM, j0, nb);
+                                   Sp, Lp, Lip, ldm, sM, j0, nb);
             else
                 hipLaunchKernelGGL(potf2_inv_kernel<128>, dim3(B), dim3(256), (128 * 129 + 8 * 16 * 17) * sizeof(double), st,
-                                   h->S, h->L, h->Li, ldm, sM, j0, nb);
+                                   Sp, Lp, Lip, ldm, sM, j0, nb);
         }
         const int rem = ml - j0 - nb;
         if (rem <= 0) break;
@@ -240,10 +240,10 @@ int run_cholesky_inverse(slamk_handle* h, int ml, hipStream_t st)
         const long long o22 = (long long)(j0 + nb) * ldm + (j0 + nb);
         // L21 = S21 inv(L11)^T
         HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_B_KLE_N>(
-                      gargs(h->S + o21, ldm, sM, h->Li + o11, ldm, sM, h->L + o21, ldm, sM, rem, nb, nb), B, st)));
+                      gargs(Sp + o21, ldm, sM, Lip + o11, ldm, sM, Lp + o21, ldm, sM, rem, nb, nb), B, st)));
         // S22 -= L21 L21^T (lower tiles only)
         HIPCHK(h, (launch_gemm<true, EPI_NONE, true, TRI_NONE>(
-                      gargs(h->L + o21, ldm, sM, h->L + o21, ldm, sM, h->S + o22, ldm, sM, rem, rem, nb, -1.0, 1.0),
+                      gargs(Lp + o21, ldm, sM, Lp + o21, ldm, sM, Sp + o22, ldm, sM, rem, rem, nb, -1.0, 1.0),
                       B, st)));
     }
     // inv(L) by recursive doubling on the block diagonal:
@@ -261,15 +261,20 @@ int run_cholesky_inverse(slamk_handle* h, int ml, hipStream_t st)
             const long long oB = (long long)(base + s) * ldm + base;         // bottom-left (M x s)
             const long long oC = (long long)(base + s) * ldm + (base + s);   // bottom-right (M x M)
             const long long s2 = (long long)2 * s * (ldm + 1);
-            GemmArgs g1 = gargs(h->L + oB, ldm, sM, h->Li + oA, ldm, sM, h->S + oB, ldm, sM, M, s, s);
+            GemmArgs g1 = gargs(Lp + oB, ldm, sM, Lip + oA, ldm, sM, Sp + oB, ldm, sM, M, s, s);
             g1.sA2 = g1.sB2 = g1.sC2 = s2; g1.nb2 = cnt;
             HIPCHK(h, (launch_gemm<false, EPI_NONE, false, TRI_B_KGE_N>(g1, B * cnt, st)));
-            GemmArgs g2 = gargs(h->Li + oC, ldm, sM, h->S + oB, ldm, sM, h->Li + oB, ldm, sM, M, s, M, -1.0, 0.0);
+            GemmArgs g2 = gargs(Lip + oC, ldm, sM, Sp + oB, ldm, sM, Lip + oB, ldm, sM, M, s, M, -1.0, 0.0);
             g2.sA2 = g2.sB2 = g2.sC2 = s2; g2.nb2 = cnt;
             HIPCHK(h, (launch_gemm<false, EPI_NONE, false, TRI_A_KLE_M>(g2, B * cnt, st)));
         }
     }
     return 0;
+}
+
+int run_cholesky_inverse(slamk_handle* h, int ml, hipStream_t st)
+{
+    return cholesky_inverse(h, h->S, h->L, h->Li, h->ldm, (long long)h->ldm * h->ldm, h->B, ml, st);
 }
 
 int run_update(slamk_handle* h, const double* qbw, const double* alt, const double* src, const double* refl,
@@ -340,7 +345,7 @@ int run_update(slamk_handle* h, const double* qbw, const double* alt, const doub
     hipLaunchKernelGGL(symmetrize_kernel, dim3((nl + 31) / 32, (nl + 31) / 32, B), dim3(256), 0, st, presym, h->fv.P,
                        ldn, sN, nl);
     // dx = K e, gate, mean update                (main.cpp:228-232)
-    hipLaunchKernelGGL(gain_kx_kernel, dim3((nl + 15) / 16, B), dim3(256), 0, st, h->fv, h->K, h->dx, ml);
+    hipLaunchKernelGGL(gain_kx_kernel, dim3((nl + 15) / 16, B), dim3(256), 0, st, h->fv, h->K, ldm, h->dx, ml);
     hipLaunchKernelGGL(gain_apply_kernel, dim3(B), dim3(256), 0, st, h->fv, h->dx, applied);
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -747,6 +752,79 @@ int slamk_update(slamk_handle* h, const double* qbw, const double* alt, int* app
     rc = slamk_sync(h, 0);
     if (applied) HIPCHK(h, hipMemcpy(applied, h->applied_d, B * sizeof(int), hipMemcpyDeviceToHost));
     return rc;
+}
+
+// ---- stage-level entry points for the row-block sharded large-map filter ---------------------------
+int slamk_stage_motion_dev(slamk_handle* h, const double* qbw_dev, const double* w_dev, const double* acc_dev,
+                           const double* dt_dev, void* stream)
+{
+    if (!h || !qbw_dev || !w_dev || !acc_dev || !dt_dev) return SLAMK_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int nl = max_nl(h);
+    hipLaunchKernelGGL(build_F_kernel, dim3((nl + 63) / 64, (nl + 3) / 4, h->B), dim3(256), 0, st, h->fv, qbw_dev,
+                       w_dev, dt_dev, h->Fm, nl);
+    hipLaunchKernelGGL(dynamics_kernel, dim3(h->B), dim3(256), 0, st, h->fv, qbw_dev, w_dev, acc_dev, dt_dev);
+    HIPCHK(h, hipGetLastError());
+    return SLAMK_OK;
+}
+
+int slamk_stage_measure_dev(slamk_handle* h, const double* qbw_dev, const double* alt_dev, const double* src_dev,
+                            const double* refl_dev, void* stream)
+{
+    if (!h || !qbw_dev) return SLAMK_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int nl = max_nl(h), ml = max_ml(h);
+    int nfmax = 0;
+    for (const auto& f : h->hf) nfmax = std::max(nfmax, f.nf);
+    hipLaunchKernelGGL(measure_kernel, dim3(std::max(1, (nfmax + 63) / 64), h->B), dim3(64), 0, st, h->fv, qbw_dev,
+                       alt_dev ? alt_dev : h->alt_d, src_dev ? src_dev : h->fv.msrc, refl_dev ? refl_dev : h->fv.mrefl,
+                       ml);
+    hipLaunchKernelGGL(build_H_kernel, dim3((nl + 63) / 64, (ml + 3) / 4, h->B), dim3(256), 0, st, h->fv, h->Hm, ml, nl);
+    HIPCHK(h, hipGetLastError());
+    return SLAMK_OK;
+}
+
+int slamk_stage_apply_dev(slamk_handle* h, const double* K_dev, int ldk, int32_t* applied_dev, void* stream)
+{
+    if (!h || !K_dev || ldk < 1) return SLAMK_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int nl = max_nl(h), ml = max_ml(h);
+    hipLaunchKernelGGL(gain_kx_kernel, dim3((nl + 15) / 16, h->B), dim3(256), 0, st, h->fv, K_dev, ldk, h->dx, ml);
+    hipLaunchKernelGGL(gain_apply_kernel, dim3(h->B), dim3(256), 0, st, h->fv, h->dx, applied_dev);
+    HIPCHK(h, hipGetLastError());
+    return SLAMK_OK;
+}
+
+int slamk_buffer_dev(slamk_handle* h, int which, double** ptr, int* rows, int* cols, int* ld)
+{
+    if (!h || !ptr || !rows || !cols || !ld) return SLAMK_EINVAL;
+    const int nl = max_nl(h), ml = max_ml(h);
+    switch (which) {
+        case 0: *ptr = h->Fm; *rows = nl; *cols = nl; *ld = h->ldn; break;          /* F */
+        case 1: *ptr = h->Hm; *rows = ml; *cols = nl; *ld = h->ldn; break;          /* H */
+        case 2: *ptr = h->fv.e; *rows = 1; *cols = ml; *ld = h->ldm; break;         /* innovation */
+        case 3: *ptr = h->fv.rdiag; *rows = 1; *cols = ml; *ld = h->ldm; break;     /* diag R */
+        case 4: *ptr = h->fv.qdiag; *rows = 1; *cols = nl; *ld = h->ldn; break;     /* diag Q */
+        case 5: *ptr = h->fv.P; *rows = nl; *cols = nl; *ld = h->ldn; break;        /* P */
+        default: return fail(h, SLAMK_EINVAL, "buffer_dev: unknown buffer %d", which);
+    }
+    return SLAMK_OK;
+}
+
+int slamk_cholesky_inverse_dev(double* S_dev, double* L_dev, double* Li_dev, int m, int ld, void* stream)
+{
+    if (!S_dev || !L_dev || !Li_dev || m < 16 || (m & 15) || ld < m) return SLAMK_EINVAL;
+    static thread_local slamk_handle scratch_handle;   // error text / profiling sink for the handle-free call
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_kernel<128>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (128 * 129 + 8 * 16 * 17) * sizeof(double));
+        attr_set = true;
+    }
+    return cholesky_inverse(&scratch_handle, S_dev, L_dev, Li_dev, ld, (long long)ld * m, 1, m, (hipStream_t)stream);
 }
 
 // ---- introspection -----------------------------------------------------------------------------------

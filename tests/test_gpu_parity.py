@@ -293,3 +293,35 @@ def test_full_size_batch_properties():
         P = fb.get_cov(b)
         assert np.all(np.isfinite(P)) and np.array_equal(P, P.T) and np.all(np.diag(P) > 0)
         assert np.linalg.eigvalsh(P).min() > 0
+
+
+def test_sharded_filter_hip_backend_single_rank():
+    """slam_amd/sharded.py with its HIP backend (world = 1: same products and stage calls as with
+    more ranks, no collective) against the oracle."""
+    torch = _torch()
+    from slam_amd.sharded import HipBackend, ShardedLargeMapFilter
+    nf, steps = 45, 7
+    st = synth.gen_stream(seed=17, nf=nf, steps=steps, churn=False)
+    so, f = helpers.run_oracle(st)
+    inp = helpers.stream_inputs(st, 7)
+    dev = torch.device("cuda", 0)
+    fb = ekf.FilterBatch(max_features=nf, batch=1)
+    fb.set_state(0, X=st.init_pos)
+    fb.frame(0, inp[0][5], inp[0][1])
+    be = HipBackend(fb, dev)
+    sh = ShardedLargeMapFilter(be, 0, 1)
+    sh.load_cov(torch.from_numpy(fb.get_cov(0)).to(dev))
+    t = lambda v: torch.tensor(np.asarray(v, dtype=np.float64), device=dev)
+    for k in range(1, steps):
+        u, quat, ang, acc, dt, matches = inp[k]
+        if u & orc.IMG:
+            fb.frame(0, matches, quat)
+        sh.predict(t(quat), t(ang), t(acc), t([dt]))
+        if u & orc.IMG:
+            applied = sh.update(t(quat))
+            be.sync()
+            assert int(applied.item()) == so[k - 1]["applied"]
+    be.sync()
+    P = sh.gather_cov().cpu().numpy()
+    assert helpers.rel_err(P, f.P) < TOL
+    assert helpers.rel_err(fb.state_vector(0), f.state_vector()) < TOL
