@@ -220,8 +220,9 @@ def main():
                 and int(applied.sum().item()) == B)
 
     if rank == 0:
-        gemm_ms = sum(v[0] for k, v in prof.items() if k.startswith("gemm"))
-        gemm_launch_groups = sum(v[1] for k, v in prof.items() if k.startswith("gemm"))
+        mfma_stage = lambda k: k.startswith("gemm") or k == "gain_solver"
+        gemm_ms = sum(v[0] for k, v in prof.items() if mfma_stage(k))
+        gemm_launch_groups = sum(v[1] for k, v in prof.items() if mfma_stage(k))
         flops_step = B * (ekf.flops_predict(n) + ekf.flops_update(n, m, 0))
         achieved = flops_step * K / (gemm_ms * 1e-3) / 1e12
         traffic = None
@@ -244,8 +245,8 @@ def main():
                        "update_form": "cholesky gain + joseph covariance", "parallelism": "filters sharded x%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "gemm_f64_kernel (all instantiations; %d launch groups timed with HIP events on the "
-                                   "launch stream)" % gemm_launch_groups,
+                         "kernel": "fp64 MFMA kernels: gemm_f64_kernel (all instantiations) + gain_solver_kernel; %d "
+                                   "launch groups timed with HIP events on the launch stream" % gemm_launch_groups,
                          "flops_per_step": flops_step, "gemm_ms_per_step": gemm_ms / K},
             "stages_ms_per_step": {k: round(v[0] / K, 4) for k, v in prof.items()},
             "outputs_sane": sane,

@@ -165,10 +165,10 @@ int slamk_dgemm_dev(int trans_b, int M, int N, int K, double alpha, const double
  * returns the achieved TFLOP/s in *tflops. */
 int slamk_mfma_f64_probe(int iters, double* tflops);
 /* Stage timing with HIP events recorded on the launch stream around each group of kernels.
- * Categories (index into ms/count, ncat >= 6): 0 per-feature and elementwise kernels,
+ * Categories (index into ms/count): 0 per-feature and elementwise kernels,
  * 1 GEMMs of the covariance predict, 2 GEMMs of the gain (W, S, Y, K), 3 GEMMs of the covariance
  * update, 4 GEMMs inside the Cholesky factorisation / triangular inverse, 5 diagonal-block
- * factorisation kernel.  slamk_profile_read synchronises, returns the accumulated milliseconds
+ * factorisation kernel, 6 fused per-filter gain solver of the small-filter path (ncat >= 7).  slamk_profile_read synchronises, returns the accumulated milliseconds
  * and scope counts since the previous read, and resets them. */
 int slamk_profile_enable(slamk_handle* h, int on);
 int slamk_profile_read(slamk_handle* h, double* ms, int* count, int ncat);

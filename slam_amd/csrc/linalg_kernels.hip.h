@@ -163,7 +163,10 @@ __global__ void __launch_bounds__(256) potf2_inv_kernel(const double* __restrict
         for (int j = tx; j < nb; j += 16) Lib[(long long)i * ld + j] = (j <= i) ? a[i * LDA + j] : 0.0;
 }
 
-// P = (A + A^T) / 2 over the padded nl x nl block (src/slam/main.cpp:567).
+// MIRROR = false: P = (A + A^T) / 2 over the padded nl x nl block (src/slam/main.cpp:567).
+// MIRROR = true : P = the symmetric matrix whose lower triangle is A's (A's upper part is not read
+//                 as data): used after products that only computed the lower tiles.
+template <bool MIRROR>
 __global__ void __launch_bounds__(256) symmetrize_kernel(const double* __restrict__ A, double* __restrict__ P,
                                                           int ld, long long stride, int nl)
 {
@@ -178,7 +181,10 @@ __global__ void __launch_bounds__(256) symmetrize_kernel(const double* __restric
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int i = by + r, j = bx + tx;
-        if (i < nl && j < nl) P[off + (long long)i * ld + j] = (A[off + (long long)i * ld + j] + t[tx][r]) / 2;
+        if (i < nl && j < nl) {
+            const double a = A[off + (long long)i * ld + j], at = t[tx][r];
+            P[off + (long long)i * ld + j] = MIRROR ? (i >= j ? a : at) : (a + at) / 2;
+        }
     }
 }
 

@@ -14,6 +14,7 @@
 
 #include "feature_kernels.hip.h"
 #include "gemm.hip.h"
+#include "gain_solver.hip.h"
 #include "linalg_kernels.hip.h"
 
 using namespace slamk;
@@ -90,7 +91,8 @@ enum ProfCat {
     PC_GEMM_COV = 3,     // I - K H, A P, (A P) A^T, (K R) K^T
     PC_GEMM_CHOL = 4,    // panel / trailing / inverse products of the factorisation
     PC_POTF2 = 5,        // diagonal-block factor + inverse
-    PC_COUNT = 6
+    PC_SOLVER = 6,       // fused per-filter gain solver (tile Cholesky + triangular solves)
+    PC_COUNT = 7
 };
 
 struct ProfScope {
@@ -277,6 +279,47 @@ int run_cholesky_inverse(slamk_handle* h, int ml, hipStream_t st)
     return cholesky_inverse(h, h->S, h->L, h->Li, h->ldm, (long long)h->ldm * h->ldm, h->B, ml, st);
 }
 
+constexpr int SOLVER_MAX_MT = 11, SOLVER_MAX_NT = 8;
+
+bool use_fused_solver(int nl, int ml) { return nl <= 16 * SOLVER_MAX_NT && ml <= 16 * SOLVER_MAX_MT; }
+
+template <int MT>
+int launch_gain_solver(slamk_handle* h, int nl, double* Lout, hipStream_t st)
+{
+    const size_t lds = ((size_t)MT * (MT + 1) / 2 * 256 + 16) * sizeof(double);
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(gain_solver_kernel<MT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const long long sM = (long long)h->ldm * h->ldm, sNM = (long long)h->ldn * h->ldm;
+    hipLaunchKernelGGL(gain_solver_kernel<MT>, dim3(h->B), dim3(512), lds, st, h->S, h->W, h->fv.rdiag, h->K, h->KR,
+                       Lout, h->ldm, sM, sNM, nl / 16);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int run_gain_solver(slamk_handle* h, int nl, int ml, hipStream_t st)
+{
+    ProfScope ps(h, PC_SOLVER, st);
+    double* Lout = (h->B <= 64) ? h->L : nullptr;     // the factor is only kept for slamk_debug_get
+    switch (ml / 16) {
+        case 1: return launch_gain_solver<1>(h, nl, Lout, st);
+        case 2: return launch_gain_solver<2>(h, nl, Lout, st);
+        case 3: return launch_gain_solver<3>(h, nl, Lout, st);
+        case 4: return launch_gain_solver<4>(h, nl, Lout, st);
+        case 5: return launch_gain_solver<5>(h, nl, Lout, st);
+        case 6: return launch_gain_solver<6>(h, nl, Lout, st);
+        case 7: return launch_gain_solver<7>(h, nl, Lout, st);
+        case 8: return launch_gain_solver<8>(h, nl, Lout, st);
+        case 9: return launch_gain_solver<9>(h, nl, Lout, st);
+        case 10: return launch_gain_solver<10>(h, nl, Lout, st);
+        case 11: return launch_gain_solver<11>(h, nl, Lout, st);
+        default: return fail(h, SLAMK_EINVAL, "gain solver: m = %d out of range", ml);
+    }
+}
+
 int run_update(slamk_handle* h, const double* qbw, const double* alt, const double* src, const double* refl,
                int* applied, hipStream_t st)
 {
@@ -307,22 +350,25 @@ int run_update(slamk_handle* h, const double* qbw, const double* alt, const doub
                   gargs(h->Hm, ldn, sMN, h->W, ldm, sNM, h->S, ldm, sM, ml, ml, nl, 1.0, 0.0, h->fv.rdiag, ldm), B,
                   st)));
     }
-    // S = L L^T, Li = inv(L)
-    int rc = run_cholesky_inverse(h, ml, st);
-    if (rc) return rc;
-    {
-    ProfScope ps(h, PC_GEMM_GAIN, st);
-    // K = W S^-1 = (W Li^T) Li                   (:547-550 solved by Cholesky instead of LU)
-    HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_B_KLE_N>(
-                  gargs(h->W, ldm, sNM, h->Li, ldm, sM, h->Y, ldm, sNM, nl, ml, ml), B, st)));
-    {
+    if (use_fused_solver(nl, ml)) {
+        // small filters: S = L L^T and K = W L^-T L^-1 (plus K R) in one workgroup per filter
+        int rc = run_gain_solver(h, nl, ml, st);
+        if (rc) return rc;
+    } else {
+        // S = L L^T, Li = inv(L)
+        int rc = run_cholesky_inverse(h, ml, st);
+        if (rc) return rc;
+        ProfScope ps(h, PC_GEMM_GAIN, st);
+        // K = W S^-1 = (W Li^T) Li                   (:547-550 solved by Cholesky instead of LU)
+        HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_B_KLE_N>(
+                      gargs(h->W, ldm, sNM, h->Li, ldm, sM, h->Y, ldm, sNM, nl, ml, ml), B, st)));
         // K and, for the Joseph form, K R (R diagonal) from the same accumulators
         GemmArgs g = gargs(h->Y, ldm, sNM, h->Li, ldm, sM, h->K, ldm, sNM, nl, ml, ml, 1.0, 0.0, h->fv.rdiag, ldm);
         g.C2 = h->KR;
         HIPCHK(h, (launch_gemm<false, EPI_DUAL_COLSCALE, false, TRI_B_KGE_N>(g, B, st)));
     }
-    }
     const double* presym = h->AP;
+    bool mirror = false;
     {
     ProfScope ps(h, PC_GEMM_COV, st);
     // A = I - K H                                (updateP, :563-565)
@@ -332,18 +378,22 @@ int run_update(slamk_handle* h, const double* qbw, const double* alt, const doub
     HIPCHK(h, (launch_gemm<false, EPI_NONE, false, TRI_NONE>(
                   gargs(h->Am, ldn, sN, h->fv.P, ldn, sN, h->AP, ldn, sN, nl, nl, nl), B, st)));
     if (h->prm.update_form == 0) {
-        // Joseph: P = AP A^T + (K R) K^T
-        HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_NONE>(
+        // Joseph: P = AP A^T + (K R) K^T, symmetric by construction: only the lower tiles are computed
+        HIPCHK(h, (launch_gemm<true, EPI_NONE, true, TRI_NONE>(
                       gargs(h->AP, ldn, sN, h->Am, ldn, sN, h->T, ldn, sN, nl, nl, nl), B, st)));
-        HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_NONE>(
+        HIPCHK(h, (launch_gemm<true, EPI_NONE, true, TRI_NONE>(
                       gargs(h->KR, ldm, sNM, h->K, ldm, sNM, h->T, ldn, sN, nl, nl, ml, 1.0, 1.0), B, st)));
         presym = h->T;
+        mirror = true;
     }
     }
     ProfScope ps(h, PC_FEATURE, st);
-    // P = (P + P^T)/2                            (:567)
-    hipLaunchKernelGGL(symmetrize_kernel, dim3((nl + 31) / 32, (nl + 31) / 32, B), dim3(256), 0, st, presym, h->fv.P,
-                       ldn, sN, nl);
+    if (mirror)   // P = the symmetric completion of the lower triangle
+        hipLaunchKernelGGL(symmetrize_kernel<true>, dim3((nl + 31) / 32, (nl + 31) / 32, B), dim3(256), 0, st, presym,
+                           h->fv.P, ldn, sN, nl);
+    else          // P = (P + P^T)/2                      (:567)
+        hipLaunchKernelGGL(symmetrize_kernel<false>, dim3((nl + 31) / 32, (nl + 31) / 32, B), dim3(256), 0, st, presym,
+                           h->fv.P, ldn, sN, nl);
     // dx = K e, gate, mean update                (main.cpp:228-232)
     hipLaunchKernelGGL(gain_kx_kernel, dim3((nl + 15) / 16, B), dim3(256), 0, st, h->fv, h->K, ldm, h->dx, ml);
     hipLaunchKernelGGL(gain_apply_kernel, dim3(B), dim3(256), 0, st, h->fv, h->dx, applied);
@@ -924,25 +974,37 @@ double slamk_flops_update(int n, int m, int update_form)
     double f = 0;
     f += gemm_flops(nl, ml, nl, false, TRI_NONE);              // W
     f += gemm_flops(ml, ml, nl, true, TRI_NONE);               // S
-    const int NB = (ml <= 1024) ? 64 : 128;
-    for (int j0 = 0; j0 < ml; j0 += NB) {
-        const int nb = std::min(NB, ml - j0), rem = ml - j0 - nb;
-        if (rem <= 0) break;
-        f += gemm_flops(rem, nb, nb, false, TRI_B_KLE_N);
-        f += gemm_flops(rem, rem, nb, true, TRI_NONE);
+    if (use_fused_solver(nl, ml)) {
+        // fused solver: 16^3-tile products (2 * 16^3 flop each) of the tile Cholesky and the two solves
+        const int MT = ml / 16, NT = nl / 16;
+        double tp = 0;
+        for (int j = 0; j < MT; ++j) {
+            const int w = MT - j - 1;
+            tp += w + w * (w + 1) / 2;
+        }
+        tp += 2.0 * NT * (MT * (MT - 1) / 2 + MT);
+        f += tp * 8192.0;
+    } else {
+        const int NB = (ml <= 1024) ? 64 : 128;
+        for (int j0 = 0; j0 < ml; j0 += NB) {
+            const int nb = std::min(NB, ml - j0), rem = ml - j0 - nb;
+            if (rem <= 0) break;
+            f += gemm_flops(rem, nb, nb, false, TRI_B_KLE_N);
+            f += gemm_flops(rem, rem, nb, true, TRI_NONE);
+        }
+        for (int s = NB; s < ml; s *= 2) {
+            const int nfull = ml / (2 * s), r = ml - nfull * 2 * s;
+            f += nfull * (gemm_flops(s, s, s, false, TRI_B_KGE_N) + gemm_flops(s, s, s, false, TRI_A_KLE_M));
+            if (r > s) f += gemm_flops(r - s, s, s, false, TRI_B_KGE_N) + gemm_flops(r - s, s, r - s, false, TRI_A_KLE_M);
+        }
+        f += gemm_flops(nl, ml, ml, false, TRI_B_KLE_N);           // Y
+        f += gemm_flops(nl, ml, ml, false, TRI_B_KGE_N);           // K
     }
-    for (int s = NB; s < ml; s *= 2) {
-        const int nfull = ml / (2 * s), r = ml - nfull * 2 * s;
-        f += nfull * (gemm_flops(s, s, s, false, TRI_B_KGE_N) + gemm_flops(s, s, s, false, TRI_A_KLE_M));
-        if (r > s) f += gemm_flops(r - s, s, s, false, TRI_B_KGE_N) + gemm_flops(r - s, s, r - s, false, TRI_A_KLE_M);
-    }
-    f += gemm_flops(nl, ml, ml, false, TRI_B_KLE_N);           // Y
-    f += gemm_flops(nl, ml, ml, false, TRI_B_KGE_N);           // K
     f += gemm_flops(nl, nl, ml, false, TRI_NONE);              // A = I - K H
     f += gemm_flops(nl, nl, nl, false, TRI_NONE);              // A P
     if (update_form == 0) {
-        f += gemm_flops(nl, nl, nl, false, TRI_NONE);          // (A P) A^T
-        f += gemm_flops(nl, nl, ml, false, TRI_NONE);          // (K R) K^T
+        f += gemm_flops(nl, nl, nl, true, TRI_NONE);           // (A P) A^T, lower tiles
+        f += gemm_flops(nl, nl, ml, true, TRI_NONE);           // (K R) K^T, lower tiles
     }
     return f;
 }
