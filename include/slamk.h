@@ -165,17 +165,20 @@ int slamk_dgemm_dev(int trans_b, int M, int N, int K, double alpha, const double
  * returns the achieved TFLOP/s in *tflops. */
 int slamk_mfma_f64_probe(int iters, double* tflops);
 /* Stage timing with HIP events recorded on the launch stream around each group of kernels.
- * Categories (index into ms/count): 0 per-feature and elementwise kernels,
- * 1 GEMMs of the covariance predict, 2 GEMMs of the gain (W, S, Y, K), 3 GEMMs of the covariance
- * update, 4 GEMMs inside the Cholesky factorisation / triangular inverse, 5 diagonal-block
- * factorisation kernel, 6 fused per-filter gain solver of the small-filter path (ncat >= 7).  slamk_profile_read synchronises, returns the accumulated milliseconds
+ * Categories (index into ms/count): 0 per-feature and elementwise kernels, 1 covariance predict
+ * (products with the compact rows of F), 2 products with the compact rows of H (P H^T, H W + R,
+ * I - K H), 3 GEMMs of the gain on the large-map path (Y, K), 4 GEMMs of the covariance update,
+ * 5 GEMMs inside the Cholesky factorisation / triangular inverse, 6 diagonal-block factorisation
+ * kernel, 7 fused per-filter gain solver of the small-filter path (ncat >= 8).
+ * slamk_profile_read synchronises, returns the accumulated milliseconds
  * and scope counts since the previous read, and resets them. */
 int slamk_profile_enable(slamk_handle* h, int on);
 int slamk_profile_read(slamk_handle* h, double* ms, int* count, int ncat);
-/* FLOPs the MFMA GEMM launches execute for one predict / one update of a filter of state dimension n
- * and measurement dimension m (tile skipping and triangular k-range trimming included; the small
- * diagonal-block factorisations and the K e product, which do not run on MFMA, excluded).  This is
- * the numerator of the fp64-matrix roofline fraction. */
+/* FLOPs the MFMA kernels execute for one predict / one update of a filter of state dimension n
+ * and measurement dimension m (tile skipping and triangular k-range trimming included; the
+ * products with the sparse Jacobians, the diagonal-block factorisations and the K e product, which
+ * do not run on MFMA, excluded: slamk_flops_predict is therefore 0).  This is the numerator of the
+ * fp64-matrix roofline fraction. */
 double slamk_flops_predict(int n);
 double slamk_flops_update(int n, int m, int update_form);
 

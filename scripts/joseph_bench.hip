@@ -1,0 +1,44 @@
+// Standalone timing of joseph_kernel<7> on 4096 filters of 32 features (ablation macros select what runs).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../slam_amd/csrc/feature_kernels.hip.h"
+#include "../slam_amd/csrc/joseph_kernel.hip.h"
+using namespace slamk;
+template <typename T> T* dev(const std::vector<T>& h, int B)
+{
+    T* d; hipMalloc(&d, h.size() * sizeof(T) * B);
+    for (int b = 0; b < B; ++b) hipMemcpy(d + b * h.size(), h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    return d;
+}
+int main()
+{
+    const int B = 4096, NT = 7, F = 32, nf = 32, ldn = 112, ldm = 208, ml = 176;
+    std::vector<double> P((size_t)ldn * ldn), K((size_t)ldn * ldm), ha(ldm * 3), hb(ldm * 3), rd(ldm, 1.0);
+    std::vector<int> rowoff(F), isref(F), nfv(1, nf);
+    for (auto& x : P) x = (double)rand() / RAND_MAX;
+    for (auto& x : K) x = ((double)rand() / RAND_MAX - 0.5) * 0.01;
+    for (auto& x : ha) x = (double)rand() / RAND_MAX;
+    for (auto& x : hb) x = (double)rand() / RAND_MAX;
+    int row = 1;
+    for (int i = 0; i < F; ++i) { isref[i] = i & 1; rowoff[i] = row; row += isref[i] ? 6 : 4; }
+    FilterView fv;
+    memset(&fv, 0, sizeof fv);
+    fv.B = B; fv.F = F; fv.ldn = ldn; fv.ldm = ldm;
+    fv.P = dev(P, B); fv.ha = dev(ha, B); fv.hb = dev(hb, B); fv.rdiag = dev(rd, B);
+    fv.rowoff = dev(rowoff, B); fv.isref = dev(isref, B); fv.nf = dev(nfv, B);
+    double* Kd = dev(K, B);
+    const size_t lds = (size_t)(NT * NT + NT) * 256 * 8;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(joseph_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        joseph_kernel<NT><<<B, 512, lds>>>(fv, Kd, ldm, (long long)ldn * ldm, ml, 0);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("%s: %.3f ms\n", VARIANT, ms);
+    }
+    return 0;
+}

@@ -21,6 +21,9 @@ struct FilterView {
     double *ha, *hb;                            // [B][ldm][3]
     int *hcs;                                   // [B][ldm]  (-1: no second group)
     double *e, *rdiag, *qdiag;                  // [B][ldm], [B][ldm], [B][ldn]
+    // motion-Jacobian rows in compact form: entries in columns 3..5, entries in columns fgs..fgs+2
+    double *fa, *fg;                            // [B][ldn][3]
+    int *fgs;                                   // [B][ldn]
     int *status;                                // [B]  bit0: reflection rows inconsistent
     double Q0, R0, qbias, gate, inv_dmax, inv_dmin, alt_override;
     int use_alt_override;

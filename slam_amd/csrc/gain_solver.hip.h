@@ -1,7 +1,7 @@
 // Fused gain solver for small filters: K = W S^-1 (and K R) from S = L L^T, one workgroup per filter.
 //
 //   in : S  m x m (lower 16-tiles valid), W  n x m,  r[m] (diagonal of R)
-//   out: K  n x m, KR = K diag(r), optionally L (lower)
+//   out: K  n x m, optionally KR = K diag(r) and L (lower)
 //   m = 16 MT with MT <= 11 (the lower tiles of S, 2 KB each, live in LDS: MT (MT+1) / 2 <= 66 tiles),
 //   n = 16 NT with NT <= 8 (one wavefront per 16 columns of W^T).
 //
@@ -68,53 +68,59 @@ __device__ __forceinline__ double rsqrt_nr(double a)
 }
 
 // One wavefront: Cholesky of the 16 x 16 tile t (lower triangle), then t := inv(L) (lower, zero above).
-// Lg != nullptr receives L (lower, zero above) at Lg[row * ldl + col].  `rdg` is a 16-double LDS
-// scratch for the reciprocals of the diagonal of L.
-__device__ inline void diag_tile_factor_invert(double* __restrict__ t, double* __restrict__ rdg,
-                                               double* __restrict__ Lg, int ldl, int lane)
+// Lg != nullptr receives L (lower, zero above) at Lg[row * ldl + col].
+// Lane (r = lane & 15, cg = lane >> 4) keeps A[r][4 cg .. 4 cg + 3] in registers; per pivot only column
+// k travels through LDS.  The body is branch-free: lanes that own nothing in a column simply keep their
+// values (selects), and every lane re-publishes one of its elements per step, which leaves the
+// not-yet-final columns of the LDS copy stale but rewrites column k + 1 just before it is read.
+__device__ inline void diag_tile_factor_invert(double* __restrict__ t, double* __restrict__ Lg, int ldl, int lane)
 {
     const int r = lane & 15, cg = lane >> 4;
-    // right-looking factorisation; lane owns row r, columns 4 cg .. 4 cg + 3 and keeps them in registers;
-    // only column k travels through LDS (written when it becomes final, read by everybody in step k)
-    double cur[4];
+    const int rb = r * 16, rm = r & 14;
+    int cb[4], cm[4];
+    double cur[4], idk[16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) cur[q] = t[tsw(r, 4 * cg + q)];
+    for (int q = 0; q < 4; ++q) {
+        cb[q] = (4 * cg + q) * 16;
+        cm[q] = (4 * cg + q) & 14;
+        cur[q] = t[rb + ((4 * cg + q) ^ rm)];
+    }
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const double akk = t[tsw(k, k)];
-        const double lrk = t[tsw(r, k)];
+        const double lrk = t[rb + (k ^ rm)];
         double lck[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) lck[q] = t[tsw(4 * cg + q, k)];
+        for (int q = 0; q < 4; ++q) lck[q] = t[cb[q] + (k ^ cm[q])];
         const double id = rsqrt_nr(akk);
+        idk[k] = id;
         const double lr = lrk * id;
+        const double colv = (r == k) ? akk * id : lr;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = 4 * cg + q;
-            if (c == k) {
-                if (r == k) { cur[q] = akk * id; rdg[k] = id; }
-                else if (r > k) cur[q] = lr;
-                t[tsw(r, k)] = cur[q];                       // column k is final
-            } else if (c > k && r >= c) {
-                cur[q] -= lr * (lck[q] * id);
-                if (c == k + 1) t[tsw(r, c)] = cur[q];       // next pivot column: everybody reads it next step
-            }
+            const double upd = cur[q] - lr * (lck[q] * id);
+            cur[q] = (c > k && r >= c) ? upd : cur[q];
+            cur[q] = (c == k) ? colv : cur[q];
         }
+        t[rb + ((4 * cg + ((k + 1) & 3)) ^ rm)] = cur[(k + 1) & 3];
     }
-    // column c of inv(L) by forward substitution, 16 lanes; row i of L is fetched in one batch
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[rb + ((4 * cg + q) ^ rm)] = cur[q];      // the factor, for the substitution below
+    // column c of inv(L) by forward substitution; row i of L is fetched in one batch (uniform addresses)
+    const int c = r;
+    double x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        double lrow[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lrow[k] = (k < i) ? t[tsw(i, k)] : 0.0;
+        double sacc = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) sacc -= lrow[k] * x[k];
+        x[i] = (i >= c) ? sacc * idk[i] : 0.0;
+    }
     if (lane < 16) {
-        const int c = lane;
-        double x[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            double lrow[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) lrow[k] = (k < i) ? t[tsw(i, k)] : 0.0;
-            double sacc = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-            for (int k = 0; k < i; ++k) sacc -= lrow[k] * x[k];
-            x[i] = (i >= c) ? sacc * rdg[i] : 0.0;
-        }
         if (Lg) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) Lg[(long long)c * ldl + i] = (i <= c) ? t[tsw(c, i)] : 0.0;   // row c of L
@@ -157,7 +163,7 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(const double* __restri
         __syncthreads();
         double* tjj = lds + tile_index(j, j) * 256;
 #ifndef SOLVER_ABLATE_DIAG
-        if (wave == 0) diag_tile_factor_invert(tjj, lds + NTILES * 256, Lb ? Lb + (long long)(16 * j) * ldm + 16 * j : nullptr, ldm, lane);
+        if (wave == 0) diag_tile_factor_invert(tjj, Lb ? Lb + (long long)(16 * j) * ldm + 16 * j : nullptr, ldm, lane);
 #endif
         __syncthreads();
         // panel: L_ij = S_ij inv(L_jj)^T
@@ -229,7 +235,7 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(const double* __restri
         y[j] = tile_mma_regB<true, false>(lds + tile_index(j, j) * 256, acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
     }
     double* Kb = K + (long long)b * sNM + (long long)(16 * wave + li) * ldm;
-    double* KRb = KR + (long long)b * sNM + (long long)(16 * wave + li) * ldm;
+    double* KRb = KR ? KR + (long long)b * sNM + (long long)(16 * wave + li) * ldm : nullptr;
     const double* rd = rdiag + (long long)b * ldm;
 #pragma unroll
     for (int j = 0; j < MT; ++j)
@@ -237,7 +243,7 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(const double* __restri
         for (int r = 0; r < 4; ++r) {
             const int q = 16 * j + lk + 4 * r;
             Kb[q] = y[j][r];
-            KRb[q] = y[j][r] * rd[q];
+            if (KRb) KRb[q] = y[j][r] * rd[q];
         }
 }
 

@@ -1,0 +1,221 @@
+// Fused covariance update for small filters, one workgroup per filter:
+//     A = I - K H,  AP = A P,  P <- AP A^T + K R K^T      (Joseph form)
+//  or P <- (AP + AP^T) / 2                                 (updateP, src/slam/main.cpp:561-569)
+// P (n x n, n = 16 NT <= 128) lives in LDS as 16 x 16 tiles, A is built in the same LDS space first and then
+// held in registers, K R is never formed in memory: HBM traffic is one read and one write of P plus two
+// reads of K.
+//
+//   phase A  A = I - K H into LDS.  H is sparse: column 6 + 3 i + c of K H only sums the 4 or 6 measurement
+//            rows of feature i (one lane per feature, rows of K read as contiguous runs), columns 0..2 sum
+//            all rows (lanes along the row of K), the rest of A is I.  Wavefront `blk` then takes its 16
+//            rows of A in MFMA operand layout (lane (li, lk) holds A[16 blk + li][4 s + lk]).
+//   phase P  P tiles replace A in LDS.
+//   phase 1  AP(blk, :) = A(blk, :) P with A from registers and P tiles from LDS; the row block is then
+//            written over P(blk, :) (all wavefronts have finished reading P by then).
+//   phase 2  wavefront `blk` owns column J = blk of the lower triangle: out(I, J), I >= J,
+//              = sum_k AP(I, k) A(J, k)   A operand from LDS, B operand = the A fragments
+//              + sum_q K(I, q) r_q K(J, q) K staged through LDS in chunks of 16 columns
+//            and stores every tile together with its mirror image.
+// Row blocks are dealt to wavefronts so that the two wavefronts sharing a SIMD (w and w + 4) own
+// columns of 8 - t and t + 1 tiles.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gain_solver.hip.h"
+
+namespace slamk {
+
+template <int NT>
+__global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double* __restrict__ K, int ldk,
+                                                      long long sK, int ml, int form)
+{
+    extern __shared__ double lds[];                     // NT * NT tiles of 256 doubles (tile (I, J) at I * NT + J)
+    double* kst = lds + NT * NT * 256;                  // + NT tiles: one 16-column chunk of K
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int blk = wave < 4 ? wave : 11 - wave;        // 0 1 2 3 7 6 5 4
+    const bool active = blk < NT;
+    const int ldn = fv.ldn;
+    double* Pb = fv.P + (long long)b * ldn * ldn;
+    const double* Kb = K + (long long)b * sK;
+    const int nf = fv.nf[b];
+
+    // ---- phase A: A = I - K H in LDS -------------------------------------------------------------------
+    for (int t = tid; t < NT * NT * 256; t += 512) lds[t] = 0.0;
+    __syncthreads();
+    {
+        const double* hb = fv.hb + (long long)b * fv.ldm * 3;
+        const double* ha = fv.ha + (long long)b * fv.ldm * 3;
+        const int half = lane >> 5, l32 = lane & 31;
+        // feature columns: lane = feature, two rows of K per wavefront and pass
+        for (int i = l32; i < nf; i += 32) {
+            const int row0 = fv.rowoff[(long long)b * fv.F + i];
+            const bool six = fv.isref[(long long)b * fv.F + i] != 0;
+            double h[18];
+#pragma unroll
+            for (int t = 0; t < 18; ++t) h[t] = (t < 12 || six) ? hb[(long long)row0 * 3 + t] : 0.0;
+            const int l0 = 6 + 3 * i;
+#pragma unroll 2
+            for (int pass = 0; pass < NT; ++pass) {
+                const int j = pass * 16 + wave * 2 + half;
+                const double* kr = Kb + (long long)j * ldk + row0;
+                double k[6];
+#pragma unroll
+                for (int t = 0; t < 6; ++t) k[t] = (t < 4 || six) ? kr[t] : 0.0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    double v = k[0] * h[c];
+#pragma unroll
+                    for (int t = 1; t < 6; ++t) v = fma(k[t], h[3 * t + c], v);
+                    const int l = l0 + c;
+                    lds[((j >> 4) * NT + (l >> 4)) * 256 + tsw(j & 15, l & 15)] = (j == l ? 1.0 : 0.0) - v;
+                }
+            }
+        }
+        // columns 0..2 and the unit diagonal outside the feature columns
+        for (int pass = 0; pass < NT; ++pass) {
+            const int j = pass * 16 + wave * 2 + half;
+            const double* kr = Kb + (long long)j * ldk;
+            double p0 = 0, p1 = 0, p2 = 0;
+            for (int q = l32; q < ml; q += 32) {
+                const double k = kr[q];
+                p0 = fma(k, ha[3 * q], p0);
+                p1 = fma(k, ha[3 * q + 1], p1);
+                p2 = fma(k, ha[3 * q + 2], p2);
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                p0 += __shfl_xor(p0, o); p1 += __shfl_xor(p1, o); p2 += __shfl_xor(p2, o);
+            }
+            if (l32 < 3) {
+                const double p = l32 == 0 ? p0 : (l32 == 1 ? p1 : p2);
+                lds[((j >> 4) * NT) * 256 + tsw(j & 15, l32)] = (j == l32 ? 1.0 : 0.0) - p;
+            }
+            if (l32 == 3 && ((j >= 3 && j < 6) || j >= 6 + 3 * nf))
+                lds[((j >> 4) * NT + (j >> 4)) * 256 + tsw(j & 15, j & 15)] = 1.0;
+        }
+    }
+    __syncthreads();
+    double af[4 * NT];
+    if (active) {
+#pragma unroll
+        for (int s = 0; s < 4 * NT; ++s) af[s] = lds[(blk * NT + (s >> 2)) * 256 + tsw(li, 4 * (s & 3) + lk)];
+    }
+    __syncthreads();
+
+    // ---- phase P: P tiles into LDS ------------------------------------------------------------------------
+    for (int t = wave; t < NT * NT; t += 8) {
+        const int I = t / NT, J = t - I * NT;
+        double* tl = lds + t * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = lk + 4 * r;
+            tl[tsw(row, li)] = Pb[(long long)(16 * I + row) * ldn + 16 * J + li];
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: AP(blk, :) = A(blk, :) P -------------------------------------------------------------
+    v4d acc[NT];
+    if (active) {
+#pragma unroll
+        for (int J = 0; J < NT; ++J) acc[J] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4 * NT; ++s) {
+            const double* col = lds + (s >> 2) * NT * 256 + tsw(4 * (s & 3) + lk, li);
+#pragma unroll
+            for (int J = 0; J < NT; ++J) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], col[J * 256], acc[J], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds[(blk * NT + J) * 256 + tsw(lk + 4 * r, li)] = acc[J][r];
+    }
+    __syncthreads();
+
+    if (form == 1) {       // P = (AP + AP^T) / 2
+        for (int t = wave; t < NT * NT; t += 8) {
+            const int I = t / NT, J = t - I * NT;
+            const double* tij = lds + t * 256;
+            const double* tji = lds + (J * NT + I) * 256;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = lk + 4 * r;
+                Pb[(long long)(16 * I + row) * ldn + 16 * J + li] = (tji[tsw(li, row)] + tij[tsw(row, li)]) / 2;
+            }
+        }
+        return;
+    }
+
+    // ---- phase 2: column J = blk of the lower triangle ---------------------------------------------------
+    const int J = blk;
+    v4d o[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) o[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (active) {
+#pragma unroll
+        for (int s = 0; s < 4 * NT; ++s) {
+            const double* rowp = lds + (J * NT + (s >> 2)) * 256 + tsw(li, 4 * (s & 3) + lk);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (J + t < NT) o[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[t * NT * 256], af[s], o[t], 0, 0, 0);
+        }
+    }
+    {
+        // K R K^T: wavefront w < NT stages tile (w, chunk) of K; the next chunk is in flight during the products
+        const double* rd = fv.rdiag + (long long)b * fv.ldm;
+        const double* ksrc = Kb + (long long)(16 * wave + lk) * ldk + li;     // element (lk + 4 r, li) of tile `wave`
+        const long long r4 = (long long)4 * ldk;
+        const bool loader = wave < NT;
+        double pre[4] = {0, 0, 0, 0};
+        if (loader) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pre[r] = ksrc[r * r4];
+        }
+        const int nchunk = ml / 16;
+        for (int c = 0; c < nchunk; ++c) {
+            if (loader) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) kst[wave * 256 + tsw(lk + 4 * r, li)] = pre[r];
+            }
+            __syncthreads();
+            if (loader && c + 1 < nchunk) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pre[r] = ksrc[r * r4 + 16 * (c + 1)];
+            }
+            if (active) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int off = tsw(li, 4 * s + lk);
+                    const double k0 = kst[J * 256 + off];
+                    const double bq = k0 * rd[16 * c + 4 * s + lk];
+                    o[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(k0, bq, o[0], 0, 0, 0);
+#pragma unroll
+                    for (int t = 1; t < NT; ++t)
+                        if (J + t < NT) o[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kst[(J + t) * 256 + off], bq, o[t], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (!active) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (J + t >= NT) break;
+        const int I = J + t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * I + lk + 4 * r, col = 16 * J + li;
+            if (row >= col) {
+                Pb[(long long)row * ldn + col] = o[t][r];
+                Pb[(long long)col * ldn + row] = o[t][r];
+            }
+        }
+    }
+}
+
+}  // namespace slamk

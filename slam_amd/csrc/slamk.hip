@@ -16,6 +16,8 @@
 #include "gemm.hip.h"
 #include "gain_solver.hip.h"
 #include "linalg_kernels.hip.h"
+#include "structured_kernels.hip.h"
+#include "joseph_kernel.hip.h"
 
 using namespace slamk;
 
@@ -85,14 +87,15 @@ int fail(slamk_handle* h, int code, const char* fmt, ...)
 
 // Stage categories reported by slamk_profile_read.
 enum ProfCat {
-    PC_FEATURE = 0,      // per-feature and elementwise kernels
-    PC_GEMM_PREDICT = 1, // P F^T, F T + Q
-    PC_GEMM_GAIN = 2,    // W, S, Y, K
-    PC_GEMM_COV = 3,     // I - K H, A P, (A P) A^T, (K R) K^T
-    PC_GEMM_CHOL = 4,    // panel / trailing / inverse products of the factorisation
-    PC_POTF2 = 5,        // diagonal-block factor + inverse
-    PC_SOLVER = 6,       // fused per-filter gain solver (tile Cholesky + triangular solves)
-    PC_COUNT = 7
+    PC_FEATURE = 0,        // per-feature and elementwise kernels
+    PC_STRUCT_PREDICT = 1, // P F^T, F T + Q with F in compact row form
+    PC_STRUCT_GAIN = 2,    // P H^T, H W + R, I - K H with H in compact row form
+    PC_GEMM_GAIN = 3,      // Y = W Li^T, K = Y Li (large maps)
+    PC_GEMM_COV = 4,       // A P, (A P) A^T, (K R) K^T
+    PC_GEMM_CHOL = 5,      // panel / trailing / inverse products of the factorisation
+    PC_POTF2 = 6,          // diagonal-block factor + inverse
+    PC_SOLVER = 7,         // fused per-filter gain solver (tile Cholesky + triangular solves)
+    PC_COUNT = 8
 };
 
 struct ProfScope {
@@ -196,6 +199,27 @@ __global__ void init_cov_kernel(double* P, int ld, long long stride, double pini
 // ------------------------------------------------------------------------------------------------
 // covariance pipelines (all launches on one stream, no host synchronisation)
 // ------------------------------------------------------------------------------------------------
+// dense F and H are only materialised for introspection (slamk_debug_get*), never for the products
+bool keep_dense(const slamk_handle* h, int nl) { return h->B <= 64 && nl <= 512; }
+
+constexpr int STRUCT_RPW = 8;        // rows per wavefront in the structured product kernels
+
+void launch_right(const RowSparse& M, const double* In, int ldi, long long sIn, double* Out, int ldo, long long sOut,
+                  int rows, int cols, int B, hipStream_t st)
+{
+    hipLaunchKernelGGL(rowsparse_right_kernel, dim3((cols + 63) / 64, (rows + 4 * STRUCT_RPW - 1) / (4 * STRUCT_RPW), B),
+                       dim3(256), 0, st, M, In, ldi, sIn, Out, ldo, sOut, rows, cols, STRUCT_RPW);
+}
+
+template <bool LOWER>
+void launch_left(const RowSparse& M, const double* In, int ldi, long long sIn, double* Out, int ldo, long long sOut,
+                 const double* diag, long long sDiag, int rows, int cols, int B, hipStream_t st)
+{
+    hipLaunchKernelGGL(rowsparse_left_kernel<LOWER>,
+                       dim3((cols + 63) / 64, (rows + 4 * STRUCT_RPW - 1) / (4 * STRUCT_RPW), B), dim3(256), 0, st, M, In,
+                       ldi, sIn, Out, ldo, sOut, diag, sDiag, rows, cols, STRUCT_RPW);
+}
+
 int run_predict(slamk_handle* h, const double* qbw, const double* w, const double* acc, const double* dt,
                 hipStream_t st)
 {
@@ -204,17 +228,19 @@ int run_predict(slamk_handle* h, const double* qbw, const double* w, const doubl
     h->last_nl = nl;
     {
         ProfScope ps(h, PC_FEATURE, st);
-        hipLaunchKernelGGL(build_F_kernel, dim3((nl + 63) / 64, (nl + 3) / 4, B), dim3(256), 0, st, h->fv, qbw, w,
-                           dt, h->Fm, nl);
+        hipLaunchKernelGGL(motion_rows_kernel, dim3((nl + 255) / 256, B), dim3(256), 0, st, h->fv, qbw, w, dt, nl);
+        if (keep_dense(h, nl))
+            hipLaunchKernelGGL(build_F_kernel, dim3((nl + 63) / 64, (nl + 3) / 4, B), dim3(256), 0, st, h->fv, qbw, w,
+                               dt, h->Fm, nl);
         hipLaunchKernelGGL(dynamics_kernel, dim3(B), dim3(256), 0, st, h->fv, qbw, w, acc, dt);
     }
-    ProfScope ps(h, PC_GEMM_PREDICT, st);
+    ProfScope ps(h, PC_STRUCT_PREDICT, st);
     // T = P F^T ; P = F T + Q      (calcP, src/slam/main.cpp:526-530, G = I)
-    HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_NONE>(
-                  gargs(h->fv.P, ldn, sN, h->Fm, ldn, sN, h->T, ldn, sN, nl, nl, nl), B, st)));
-    HIPCHK(h, (launch_gemm<false, EPI_DIAG_ADD, false, TRI_NONE>(
-                  gargs(h->Fm, ldn, sN, h->T, ldn, sN, h->fv.P, ldn, sN, nl, nl, nl, 1.0, 0.0, h->fv.qdiag, ldn), B,
-                  st)));
+    const int nt = (nl + 2) / 3;
+    hipLaunchKernelGGL(predict_cov_kernel, dim3((nt + 15) / 16, (nt + 15) / 16, B), dim3(256), 0, st, h->fv, h->fv.P,
+                       h->T, nl);
+    std::swap(h->fv.P, h->T);          // T is whichever of the two covariance-sized buffers is not P
+    HIPCHK(h, hipGetLastError());
     return 0;
 }
 
@@ -294,8 +320,8 @@ int launch_gain_solver(slamk_handle* h, int nl, double* Lout, hipStream_t st)
         attr_done = true;
     }
     const long long sM = (long long)h->ldm * h->ldm, sNM = (long long)h->ldn * h->ldm;
-    hipLaunchKernelGGL(gain_solver_kernel<MT>, dim3(h->B), dim3(512), lds, st, h->S, h->W, h->fv.rdiag, h->K, h->KR,
-                       Lout, h->ldm, sM, sNM, nl / 16);
+    hipLaunchKernelGGL(gain_solver_kernel<MT>, dim3(h->B), dim3(512), lds, st, h->S, h->W, h->fv.rdiag, h->K,
+                       (double*)nullptr, Lout, h->ldm, sM, sNM, nl / 16);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -320,13 +346,44 @@ int run_gain_solver(slamk_handle* h, int nl, int ml, hipStream_t st)
     }
 }
 
+template <int NT>
+int launch_joseph(slamk_handle* h, int ml, hipStream_t st)
+{
+    const size_t lds = (size_t)(NT * NT + NT) * 256 * sizeof(double);
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(joseph_kernel<NT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(joseph_kernel<NT>, dim3(h->B), dim3(512), lds, st, h->fv, h->K, h->ldm,
+                       (long long)h->ldn * h->ldm, ml, h->prm.update_form);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int run_joseph(slamk_handle* h, int nl, int ml, hipStream_t st)
+{
+    ProfScope ps(h, PC_GEMM_COV, st);
+    switch (nl / 16) {
+        case 1: return launch_joseph<1>(h, ml, st);
+        case 2: return launch_joseph<2>(h, ml, st);
+        case 3: return launch_joseph<3>(h, ml, st);
+        case 4: return launch_joseph<4>(h, ml, st);
+        case 5: return launch_joseph<5>(h, ml, st);
+        case 6: return launch_joseph<6>(h, ml, st);
+        case 7: return launch_joseph<7>(h, ml, st);
+        case 8: return launch_joseph<8>(h, ml, st);
+        default: return fail(h, SLAMK_EINVAL, "fused covariance update: n = %d out of range", nl);
+    }
+}
+
 int run_update(slamk_handle* h, const double* qbw, const double* alt, const double* src, const double* refl,
                int* applied, hipStream_t st)
 {
     const int B = h->B, ldn = h->ldn, ldm = h->ldm;
     const int nl = max_nl(h), ml = max_ml(h);
-    const long long sN = (long long)ldn * ldn, sNM = (long long)ldn * ldm, sMN = (long long)ldm * ldn,
-                    sM = (long long)ldm * ldm;
+    const long long sN = (long long)ldn * ldn, sNM = (long long)ldn * ldm, sM = (long long)ldm * ldm;
     h->last_nl = nl; h->last_ml = ml;
     int nfmax = 0;
     for (const auto& f : h->hf) nfmax = std::max(nfmax, f.nf);
@@ -337,18 +394,17 @@ int run_update(slamk_handle* h, const double* qbw, const double* alt, const doub
         ProfScope ps(h, PC_FEATURE, st);
         hipLaunchKernelGGL(measure_kernel, dim3(std::max(1, (nfmax + 63) / 64), B), dim3(64), 0, st, h->fv, qbw, alt,
                            src, refl, ml);
-        hipLaunchKernelGGL(build_H_kernel, dim3((nl + 63) / 64, (ml + 3) / 4, B), dim3(256), 0, st, h->fv, h->Hm, ml,
-                           nl);
+        if (keep_dense(h, nl))
+            hipLaunchKernelGGL(build_H_kernel, dim3((nl + 63) / 64, (ml + 3) / 4, B), dim3(256), 0, st, h->fv, h->Hm,
+                               ml, nl);
     }
+    const RowSparse MH{h->fv.ha, h->fv.hb, h->fv.hcs, ldm, 0};
     {
-    ProfScope ps(h, PC_GEMM_GAIN, st);
+    ProfScope ps(h, PC_STRUCT_GAIN, st);
     // W = P H^T                                  (calcK, src/slam/main.cpp:545)
-    HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_NONE>(
-                  gargs(h->fv.P, ldn, sN, h->Hm, ldn, sMN, h->W, ldm, sNM, nl, ml, nl), B, st)));
-    // S = H W + R, lower tiles                   (:541-543)
-    HIPCHK(h, (launch_gemm<false, EPI_DIAG_ADD, true, TRI_NONE>(
-                  gargs(h->Hm, ldn, sMN, h->W, ldm, sNM, h->S, ldm, sM, ml, ml, nl, 1.0, 0.0, h->fv.rdiag, ldm), B,
-                  st)));
+    launch_right(MH, h->fv.P, ldn, sN, h->W, ldm, sNM, nl, ml, B, st);
+    // S = H W + R, lower part                    (:541-543)
+    launch_left<true>(MH, h->W, ldm, sNM, h->S, ldm, sM, h->fv.rdiag, ldm, ml, ml, B, st);
     }
     if (use_fused_solver(nl, ml)) {
         // small filters: S = L L^T and K = W L^-T L^-1 (plus K R) in one workgroup per filter
@@ -367,33 +423,45 @@ int run_update(slamk_handle* h, const double* qbw, const double* alt, const doub
         g.C2 = h->KR;
         HIPCHK(h, (launch_gemm<false, EPI_DUAL_COLSCALE, false, TRI_B_KGE_N>(g, B, st)));
     }
-    const double* presym = h->AP;
-    bool mirror = false;
-    {
-    ProfScope ps(h, PC_GEMM_COV, st);
-    // A = I - K H                                (updateP, :563-565)
-    HIPCHK(h, (launch_gemm<false, EPI_EYE_MINUS, false, TRI_NONE>(
-                  gargs(h->K, ldm, sNM, h->Hm, ldn, sMN, h->Am, ldn, sN, nl, nl, ml), B, st)));
-    // AP = A P
-    HIPCHK(h, (launch_gemm<false, EPI_NONE, false, TRI_NONE>(
-                  gargs(h->Am, ldn, sN, h->fv.P, ldn, sN, h->AP, ldn, sN, nl, nl, nl), B, st)));
-    if (h->prm.update_form == 0) {
-        // Joseph: P = AP A^T + (K R) K^T, symmetric by construction: only the lower tiles are computed
-        HIPCHK(h, (launch_gemm<true, EPI_NONE, true, TRI_NONE>(
-                      gargs(h->AP, ldn, sN, h->Am, ldn, sN, h->T, ldn, sN, nl, nl, nl), B, st)));
-        HIPCHK(h, (launch_gemm<true, EPI_NONE, true, TRI_NONE>(
-                      gargs(h->KR, ldm, sNM, h->K, ldm, sNM, h->T, ldn, sN, nl, nl, ml, 1.0, 1.0), B, st)));
-        presym = h->T;
-        mirror = true;
+    if (use_fused_solver(nl, ml)) {
+        // small filters: A = I - K H, A P and the Joseph (or simple) form in one workgroup per filter
+        int rc = run_joseph(h, nl, ml, st);
+        if (rc) return rc;
+    } else {
+        const double* presym = h->AP;
+        bool mirror = false;
+        {
+        ProfScope ps(h, PC_STRUCT_GAIN, st);
+        // A = I - K H                                (updateP, :563-565)
+        hipLaunchKernelGGL(eye_minus_kh_kernel, dim3((nl + 63) / 64, (nl + 4 * STRUCT_RPW - 1) / (4 * STRUCT_RPW), B),
+                           dim3(256), 0, st, h->fv, h->K, ldm, sNM, h->Am, nl, STRUCT_RPW);
+        hipLaunchKernelGGL(eye_minus_kh_xcols_kernel, dim3((nl + 3) / 4, B), dim3(256), 0, st, h->fv, h->K, ldm, sNM, h->Am,
+                           nl, ml);
+        }
+        {
+        ProfScope ps(h, PC_GEMM_COV, st);
+        // AP = A P
+        HIPCHK(h, (launch_gemm<false, EPI_NONE, false, TRI_NONE>(
+                      gargs(h->Am, ldn, sN, h->fv.P, ldn, sN, h->AP, ldn, sN, nl, nl, nl), B, st)));
+        if (h->prm.update_form == 0) {
+            // Joseph: P = AP A^T + (K R) K^T, symmetric by construction: only the lower tiles are computed
+            HIPCHK(h, (launch_gemm<true, EPI_NONE, true, TRI_NONE>(
+                          gargs(h->AP, ldn, sN, h->Am, ldn, sN, h->T, ldn, sN, nl, nl, nl), B, st)));
+            HIPCHK(h, (launch_gemm<true, EPI_NONE, true, TRI_NONE>(
+                          gargs(h->KR, ldm, sNM, h->K, ldm, sNM, h->T, ldn, sN, nl, nl, ml, 1.0, 1.0), B, st)));
+            presym = h->T;
+            mirror = true;
+        }
+        }
+        ProfScope ps(h, PC_FEATURE, st);
+        if (mirror)   // P = the symmetric completion of the lower triangle
+            hipLaunchKernelGGL(symmetrize_kernel<true>, dim3((nl + 31) / 32, (nl + 31) / 32, B), dim3(256), 0, st, presym,
+                               h->fv.P, ldn, sN, nl);
+        else          // P = (P + P^T)/2                      (:567)
+            hipLaunchKernelGGL(symmetrize_kernel<false>, dim3((nl + 31) / 32, (nl + 31) / 32, B), dim3(256), 0, st, presym,
+                               h->fv.P, ldn, sN, nl);
     }
-    }
-    ProfScope ps(h, PC_FEATURE, st);
-    if (mirror)   // P = the symmetric completion of the lower triangle
-        hipLaunchKernelGGL(symmetrize_kernel<true>, dim3((nl + 31) / 32, (nl + 31) / 32, B), dim3(256), 0, st, presym,
-                           h->fv.P, ldn, sN, nl);
-    else          // P = (P + P^T)/2                      (:567)
-        hipLaunchKernelGGL(symmetrize_kernel<false>, dim3((nl + 31) / 32, (nl + 31) / 32, B), dim3(256), 0, st, presym,
-                           h->fv.P, ldn, sN, nl);
+    ProfScope ps_tail(h, PC_FEATURE, st);
     // dx = K e, gate, mean update                (main.cpp:228-232)
     hipLaunchKernelGGL(gain_kx_kernel, dim3((nl + 15) / 16, B), dim3(256), 0, st, h->fv, h->K, ldm, h->dx, ml);
     hipLaunchKernelGGL(gain_apply_kernel, dim3(B), dim3(256), 0, st, h->fv, h->dx, applied);
@@ -462,6 +530,7 @@ int slamk_create(const slamk_params* p, int max_features, int batch, int device,
     rc |= dalloc(h, &v.P, B * ldn * ldn);
     rc |= dalloc(h, &v.ha, B * ldm * 3); rc |= dalloc(h, &v.hb, B * ldm * 3); rc |= dalloc(h, &v.hcs, B * ldm);
     rc |= dalloc(h, &v.e, B * ldm); rc |= dalloc(h, &v.rdiag, B * ldm); rc |= dalloc(h, &v.qdiag, B * ldn);
+    rc |= dalloc(h, &v.fa, B * ldn * 3); rc |= dalloc(h, &v.fg, B * ldn * 3); rc |= dalloc(h, &v.fgs, B * ldn);
     rc |= dalloc(h, &h->Fm, B * ldn * ldn); rc |= dalloc(h, &h->T, B * ldn * ldn);
     rc |= dalloc(h, &h->Am, B * ldn * ldn); rc |= dalloc(h, &h->AP, B * ldn * ldn);
     rc |= dalloc(h, &h->Hm, B * ldm * ldn);
@@ -964,16 +1033,14 @@ int slamk_profile_read(slamk_handle* h, double* ms, int* count, int ncat)
 
 double slamk_flops_predict(int n)
 {
-    const int nl = pad16(n);
-    return 2 * gemm_flops(nl, nl, nl, false, TRI_NONE);
+    (void)n;
+    return 0.0;        // the predict products run on the compact rows of F: no MFMA work
 }
 
 double slamk_flops_update(int n, int m, int update_form)
 {
     const int nl = pad16(n), ml = pad16(m);
     double f = 0;
-    f += gemm_flops(nl, ml, nl, false, TRI_NONE);              // W
-    f += gemm_flops(ml, ml, nl, true, TRI_NONE);               // S
     if (use_fused_solver(nl, ml)) {
         // fused solver: 16^3-tile products (2 * 16^3 flop each) of the tile Cholesky and the two solves
         const int MT = ml / 16, NT = nl / 16;
@@ -983,7 +1050,10 @@ double slamk_flops_update(int n, int m, int update_form)
             tp += w + w * (w + 1) / 2;
         }
         tp += 2.0 * NT * (MT * (MT - 1) / 2 + MT);
-        f += tp * 8192.0;
+        // fused covariance update: A P, then the lower tiles of (A P) A^T + K R K^T
+        tp += (double)NT * NT * NT;
+        if (update_form == 0) tp += NT * (NT + 1) / 2 * (double)(NT + MT);
+        return tp * 8192.0;
     } else {
         const int NB = (ml <= 1024) ? 64 : 128;
         for (int j0 = 0; j0 < ml; j0 += NB) {
@@ -1000,7 +1070,6 @@ double slamk_flops_update(int n, int m, int update_form)
         f += gemm_flops(nl, ml, ml, false, TRI_B_KLE_N);           // Y
         f += gemm_flops(nl, ml, ml, false, TRI_B_KGE_N);           // K
     }
-    f += gemm_flops(nl, nl, ml, false, TRI_NONE);              // A = I - K H
     f += gemm_flops(nl, nl, nl, false, TRI_NONE);              // A P
     if (update_form == 0) {
         f += gemm_flops(nl, nl, nl, true, TRI_NONE);           // (A P) A^T, lower tiles

@@ -160,8 +160,8 @@ class FilterBatch:
     def sync(self, stream=0):
         self._chk(self.L.slamk_sync(self.h, stream))
 
-    PROFILE_STAGES = ("feature_kernels", "gemm_predict", "gemm_gain", "gemm_cov_update", "gemm_cholesky", "potf2_inv",
-                      "gain_solver")
+    PROFILE_STAGES = ("feature_kernels", "struct_predict", "struct_gain", "gemm_gain", "gemm_cov_update",
+                      "gemm_cholesky", "potf2_inv", "gain_solver")
 
     def profile_enable(self, on=True):
         self._chk(self.L.slamk_profile_enable(self.h, int(bool(on))))
