@@ -24,7 +24,7 @@ int main()
         hipMemcpy(W + b * sNM, hW.data(), sNM * 8, hipMemcpyHostToDevice);
         hipMemcpy(r + (size_t)b * ldm, hr.data(), ldm * 8, hipMemcpyHostToDevice);
     }
-    const size_t lds = ((size_t)MT * (MT + 1) / 2 * 256 + 16) * 8;
+    const size_t lds = ((size_t)MT * (MT + 1) / 2 * 256 + 256) * 8;
     hipFuncSetAttribute(reinterpret_cast<const void*>(gain_solver_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {

@@ -67,68 +67,149 @@ __device__ __forceinline__ double rsqrt_nr(double a)
     return y;
 }
 
-// One wavefront: Cholesky of the 16 x 16 tile t (lower triangle), then t := inv(L) (lower, zero above).
-// Lg != nullptr receives L (lower, zero above) at Lg[row * ldl + col].
-// Lane (r = lane & 15, cg = lane >> 4) keeps A[r][4 cg .. 4 cg + 3] in registers; per pivot only column
-// k travels through LDS.  The body is branch-free: lanes that own nothing in a column simply keep their
-// values (selects), and every lane re-publishes one of its elements per step, which leaves the
-// not-yet-final columns of the LDS copy stale but rewrites column k + 1 just before it is read.
-__device__ inline void diag_tile_factor_invert(double* __restrict__ t, double* __restrict__ Lg, int ldl, int lane)
+// Lower triangle of a 4 x 4 block packed by rows: (i, j) at i (i + 1) / 2 + j.
+// l = chol(d), id[k] = 1 / l_kk.
+__device__ __forceinline__ void chol4(const double* d, double* l, double* id)
 {
-    const int r = lane & 15, cg = lane >> 4;
-    const int rb = r * 16, rm = r & 14;
-    int cb[4], cm[4];
-    double cur[4], idk[16];
+    id[0] = rsqrt_nr(d[0]);
+    l[0] = d[0] * id[0];
+    l[1] = d[1] * id[0]; l[3] = d[3] * id[0]; l[6] = d[6] * id[0];
+    const double a11 = fma(-l[1], l[1], d[2]);
+    id[1] = rsqrt_nr(a11);
+    l[2] = a11 * id[1];
+    l[4] = fma(-l[3], l[1], d[4]) * id[1];
+    l[7] = fma(-l[6], l[1], d[7]) * id[1];
+    const double a22 = fma(-l[4], l[4], fma(-l[3], l[3], d[5]));
+    id[2] = rsqrt_nr(a22);
+    l[5] = a22 * id[2];
+    l[8] = fma(-l[7], l[4], fma(-l[6], l[3], d[8])) * id[2];
+    const double a33 = fma(-l[8], l[8], fma(-l[7], l[7], fma(-l[6], l[6], d[9])));
+    id[3] = rsqrt_nr(a33);
+    l[9] = a33 * id[3];
+}
+
+// x = a inv(l)^T for one row a of four entries.
+__device__ __forceinline__ void solve4(const double* a, const double* l, const double* id, double* x)
+{
+    x[0] = a[0] * id[0];
+    x[1] = fma(-x[0], l[1], a[1]) * id[1];
+    x[2] = fma(-x[1], l[4], fma(-x[0], l[3], a[2])) * id[2];
+    x[3] = fma(-x[2], l[8], fma(-x[1], l[7], fma(-x[0], l[6], a[3]))) * id[3];
+}
+
+// x = inv(l), packed like l.
+__device__ __forceinline__ void inv4(const double* l, const double* id, double* x)
+{
+    x[0] = id[0]; x[2] = id[1]; x[5] = id[2]; x[9] = id[3];
+    x[1] = -id[1] * (l[1] * x[0]);
+    x[3] = -id[2] * fma(l[4], x[1], l[3] * x[0]);
+    x[6] = -id[3] * fma(l[8], x[3], fma(l[7], x[1], l[6] * x[0]));
+    x[4] = -id[2] * (l[4] * x[2]);
+    x[7] = -id[3] * fma(l[8], x[4], l[7] * x[2]);
+    x[8] = -id[3] * (l[8] * x[5]);
+}
+
+// One wavefront: Cholesky of the symmetric 16 x 16 tile t, then t := inv(L) (lower, zero above).
+// xs is a scratch tile; Lg != nullptr receives L (lower, zero above) at Lg[row * ldl + col].
+// Lane (r = lane & 15, cg = lane >> 4) owns A[r][4 cg .. 4 cg + 3] in registers.  The factorisation is
+// right-looking in four steps of four columns: every lane factors the 4 x 4 pivot block itself and solves
+// its own row and the rows of its four columns against it, so one LDS round trip per step is the only
+// communication.  The inverse is formed row by row from the diagonal block leftwards,
+//     X_bc = -(sum_{c < k <= b} X_bk L_kc) inv(L_cc),
+// again one LDS round trip per block column.  No divergent branches: lanes that own nothing in a step
+// keep their values through selects.
+__device__ inline void diag_tile_factor_invert(double* t, double* xs, double* __restrict__ Lg, int ldl, int lane)
+{
+    const int r = lane & 15, cg = lane >> 4, b = r >> 2, i = r & 3;
+    double cur[4], idall[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cur[q] = t[tsw(r, 4 * cg + q)];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        if (kb > 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[tsw(r, 4 * cg + q)] = cur[q];
+        }
+        double d[10], l[10], id[4], ar[4], xr[4];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int jj = 0; jj <= ii; ++jj) d[ii * (ii + 1) / 2 + jj] = t[tsw(4 * kb + ii, 4 * kb + jj)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ar[q] = t[tsw(r, 4 * kb + q)];
+        double ac[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ac[p][q] = t[tsw(4 * cg + p, 4 * kb + q)];
+        chol4(d, l, id);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) idall[4 * kb + q] = id[q];
+        solve4(ar, l, id, xr);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            double xc[4];
+            solve4(ac[p], l, id, xc);
+            double v = cur[p];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v = fma(-xr[q], xc[q], v);
+            const double own = (r >= 4 * kb + p) ? xr[p] : 0.0;
+            cur[p] = (cg > kb) ? v : ((cg == kb) ? own : cur[p]);
+        }
+    }
+    // the factor, zero above the diagonal
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        cb[q] = (4 * cg + q) * 16;
-        cm[q] = (4 * cg + q) & 14;
-        cur[q] = t[rb + ((4 * cg + q) ^ rm)];
+        cur[q] = (4 * cg + q <= r) ? cur[q] : 0.0;
+        t[tsw(r, 4 * cg + q)] = cur[q];
+    }
+    if (Lg) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Lg[(long long)r * ldl + 4 * cg + q] = cur[q];
+    }
+    // inverse of the diagonal block of this lane's column group
+    double lc[10], idc[4], xc[10];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int jj = 0; jj <= ii; ++jj) lc[ii * (ii + 1) / 2 + jj] = t[tsw(4 * cg + ii, 4 * cg + jj)];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        idc[q] = cg == 0 ? idall[q] : (cg == 1 ? idall[4 + q] : (cg == 2 ? idall[8 + q] : idall[12 + q]));
+    inv4(lc, idc, xc);
+    double xrow[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const double v = i == 0 ? (q == 0 ? xc[0] : 0.0)
+                       : i == 1 ? (q <= 1 ? xc[1 + q] : 0.0)
+                       : i == 2 ? (q <= 2 ? xc[3 + q] : 0.0) : xc[6 + q];
+        xrow[q] = (cg == b) ? v : 0.0;
+        xs[tsw(r, 4 * cg + q)] = xrow[q];
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const double akk = t[tsw(k, k)];
-        const double lrk = t[rb + (k ^ rm)];
-        double lck[4];
+    for (int k = 1; k < 4; ++k) {
+        double v[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) lck[q] = t[cb[q] + (k ^ cm[q])];
-        const double id = rsqrt_nr(akk);
-        idk[k] = id;
-        const double lr = lrk * id;
-        const double colv = (r == k) ? akk * id : lr;
+        for (int a = 0; a < 4 * k; ++a) {
+            const int ap = (4 * cg + 4 + a) & 15;          // only lanes with b - cg == k keep the result
+            const double xv = xs[tsw(r, ap)];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = fma(xv, t[tsw(ap, 4 * cg + c)], v[c]);
+        }
+        const bool act = (b - cg == k);
+        double o[4];
+        o[0] = -fma(v[3], xc[6], fma(v[2], xc[3], fma(v[1], xc[1], v[0] * xc[0])));
+        o[1] = -fma(v[3], xc[7], fma(v[2], xc[4], v[1] * xc[2]));
+        o[2] = -fma(v[3], xc[8], v[2] * xc[5]);
+        o[3] = -(v[3] * xc[9]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int c = 4 * cg + q;
-            const double upd = cur[q] - lr * (lck[q] * id);
-            cur[q] = (c > k && r >= c) ? upd : cur[q];
-            cur[q] = (c == k) ? colv : cur[q];
+            xrow[q] = act ? o[q] : xrow[q];
+            xs[tsw(r, 4 * cg + q)] = xrow[q];
         }
-        t[rb + ((4 * cg + ((k + 1) & 3)) ^ rm)] = cur[(k + 1) & 3];
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) t[rb + ((4 * cg + q) ^ rm)] = cur[q];      // the factor, for the substitution below
-    // column c of inv(L) by forward substitution; row i of L is fetched in one batch (uniform addresses)
-    const int c = r;
-    double x[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        double lrow[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) lrow[k] = (k < i) ? t[tsw(i, k)] : 0.0;
-        double sacc = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < i; ++k) sacc -= lrow[k] * x[k];
-        x[i] = (i >= c) ? sacc * idk[i] : 0.0;
-    }
-    if (lane < 16) {
-        if (Lg) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) Lg[(long long)c * ldl + i] = (i <= c) ? t[tsw(c, i)] : 0.0;   // row c of L
-        }
-        // every lane has read what it needs of L before the tile is overwritten (same wavefront, in order)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t[tsw(i, c)] = x[i];
-    }
+    for (int q = 0; q < 4; ++q) t[tsw(r, 4 * cg + q)] = xrow[q];
 }
 
 template <int MT>
@@ -137,7 +218,7 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(const double* __restri
                                                            double* __restrict__ KR, double* __restrict__ L, int ldm,
                                                            long long sM, long long sNM, int NT)
 {
-    extern __shared__ double lds[];                     // MT (MT + 1) / 2 tiles of 256 doubles + 16
+    extern __shared__ double lds[];                     // MT (MT + 1) / 2 tiles of 256 doubles + one scratch tile
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -163,7 +244,7 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(const double* __restri
         __syncthreads();
         double* tjj = lds + tile_index(j, j) * 256;
 #ifndef SOLVER_ABLATE_DIAG
-        if (wave == 0) diag_tile_factor_invert(tjj, Lb ? Lb + (long long)(16 * j) * ldm + 16 * j : nullptr, ldm, lane);
+        if (wave == 0) diag_tile_factor_invert(tjj, lds + NTILES * 256, Lb ? Lb + (long long)(16 * j) * ldm + 16 * j : nullptr, ldm, lane);
 #endif
         __syncthreads();
         // panel: L_ij = S_ij inv(L_jj)^T

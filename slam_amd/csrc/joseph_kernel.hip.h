@@ -23,6 +23,10 @@
 
 #include "gain_solver.hip.h"
 
+#ifndef JOSEPH_STOP
+#define JOSEPH_STOP 0      // > 0: timing builds that leave the kernel after a phase
+#endif
+
 namespace slamk {
 
 template <int NT>
@@ -30,7 +34,9 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
                                                       long long sK, int ml, int form)
 {
     extern __shared__ double lds[];                     // NT * NT tiles of 256 doubles (tile (I, J) at I * NT + J)
-    double* kst = lds + NT * NT * 256;                  // + NT tiles: one 16-column chunk of K
+    constexpr int KBUF = (NT <= 7) ? 2 : 1;             // chunk buffers of K (LDS holds two up to NT = 7)
+    double* kst = lds + NT * NT * 256;                  // + KBUF * NT tiles: 16-column chunks of K
+    double* rds = kst + KBUF * NT * 256;                // + 256: diagonal of R
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -41,59 +47,70 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
     const double* Kb = K + (long long)b * sK;
     const int nf = fv.nf[b];
 
+    // P tiles of this wavefront go to registers first: their latency hides behind phase A
+    constexpr int PT = (NT * NT + 7) / 8;
+    double pre_p[PT][4];
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+        const int t = wave + 8 * u;
+        const int I = t / NT, J = t - I * NT;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            pre_p[u][r] = (t < NT * NT) ? Pb[(long long)(16 * I + lk + 4 * r) * ldn + 16 * J + li] : 0.0;
+    }
+
     // ---- phase A: A = I - K H in LDS -------------------------------------------------------------------
     for (int t = tid; t < NT * NT * 256; t += 512) lds[t] = 0.0;
+    for (int t = tid; t < ml; t += 512) rds[t] = fv.rdiag[(long long)b * fv.ldm + t];
+    __syncthreads();
+    if (tid < 16 * NT) lds[((tid >> 4) * (NT + 1)) * 256 + tsw(tid & 15, tid & 15)] = 1.0;
     __syncthreads();
     {
         const double* hb = fv.hb + (long long)b * fv.ldm * 3;
         const double* ha = fv.ha + (long long)b * fv.ldm * 3;
         const int half = lane >> 5, l32 = lane & 31;
-        // feature columns: lane = feature, two rows of K per wavefront and pass
-        for (int i = l32; i < nf; i += 32) {
-            const int row0 = fv.rowoff[(long long)b * fv.F + i];
-            const bool six = fv.isref[(long long)b * fv.F + i] != 0;
-            double h[18];
+        // lane = feature i: columns 6 + 3 i .. + 2 from its 4 or 6 measurement rows, and its share of the
+        // position columns 0..2 (summed over the lanes; lane 0 also carries the altitude row 0)
+        for (int i0 = 0; i0 < nf; i0 += 32) {
+            const int i = i0 + l32;
+            const bool live = i < nf;
+            const int row0 = live ? fv.rowoff[(long long)b * fv.F + i] : 0;
+            const bool six = live && fv.isref[(long long)b * fv.F + i] != 0;
+            double h[18], g[18];
 #pragma unroll
-            for (int t = 0; t < 18; ++t) h[t] = (t < 12 || six) ? hb[(long long)row0 * 3 + t] : 0.0;
+            for (int t = 0; t < 18; ++t) {
+                const bool on = live && (t < 12 || six);
+                h[t] = on ? hb[(long long)row0 * 3 + t] : 0.0;
+                g[t] = on ? ha[(long long)row0 * 3 + t] : 0.0;
+            }
+            const bool alt = (i == 0);
+            const double g0 = alt ? ha[0] : 0.0, g1 = alt ? ha[1] : 0.0, g2 = alt ? ha[2] : 0.0;
             const int l0 = 6 + 3 * i;
-#pragma unroll 2
+#pragma unroll
             for (int pass = 0; pass < NT; ++pass) {
                 const int j = pass * 16 + wave * 2 + half;
-                const double* kr = Kb + (long long)j * ldk + row0;
+                const double* kr = Kb + (long long)j * ldk;
                 double k[6];
 #pragma unroll
-                for (int t = 0; t < 6; ++t) k[t] = (t < 4 || six) ? kr[t] : 0.0;
+                for (int t = 0; t < 6; ++t) k[t] = (live && (t < 4 || six)) ? kr[row0 + t] : 0.0;
+                const double ka = alt ? kr[0] : 0.0;
+                double x[3] = {ka * g0, ka * g1, ka * g2};
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     double v = k[0] * h[c];
 #pragma unroll
                     for (int t = 1; t < 6; ++t) v = fma(k[t], h[3 * t + c], v);
-                    const int l = l0 + c;
-                    lds[((j >> 4) * NT + (l >> 4)) * 256 + tsw(j & 15, l & 15)] = (j == l ? 1.0 : 0.0) - v;
-                }
-            }
-        }
-        // columns 0..2 and the unit diagonal outside the feature columns
-        for (int pass = 0; pass < NT; ++pass) {
-            const int j = pass * 16 + wave * 2 + half;
-            const double* kr = Kb + (long long)j * ldk;
-            double p0 = 0, p1 = 0, p2 = 0;
-            for (int q = l32; q < ml; q += 32) {
-                const double k = kr[q];
-                p0 = fma(k, ha[3 * q], p0);
-                p1 = fma(k, ha[3 * q + 1], p1);
-                p2 = fma(k, ha[3 * q + 2], p2);
-            }
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) {
-                p0 += __shfl_xor(p0, o); p1 += __shfl_xor(p1, o); p2 += __shfl_xor(p2, o);
+                    for (int t = 0; t < 6; ++t) x[c] = fma(k[t], g[3 * t + c], x[c]);
+                    const int l = l0 + c;
+                    if (live) lds[((j >> 4) * NT + (l >> 4)) * 256 + tsw(j & 15, l & 15)] = (j == l ? 1.0 : 0.0) - v;
+                }
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) {
+                    x[0] += __shfl_xor(x[0], o); x[1] += __shfl_xor(x[1], o); x[2] += __shfl_xor(x[2], o);
+                }
+                if (l32 < 3) lds[((j >> 4) * NT) * 256 + tsw(j & 15, l32)] -= (l32 == 0 ? x[0] : (l32 == 1 ? x[1] : x[2]));
             }
-            if (l32 < 3) {
-                const double p = l32 == 0 ? p0 : (l32 == 1 ? p1 : p2);
-                lds[((j >> 4) * NT) * 256 + tsw(j & 15, l32)] = (j == l32 ? 1.0 : 0.0) - p;
-            }
-            if (l32 == 3 && ((j >= 3 && j < 6) || j >= 6 + 3 * nf))
-                lds[((j >> 4) * NT + (j >> 4)) * 256 + tsw(j & 15, j & 15)] = 1.0;
         }
     }
     __syncthreads();
@@ -103,18 +120,23 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
         for (int s = 0; s < 4 * NT; ++s) af[s] = lds[(blk * NT + (s >> 2)) * 256 + tsw(li, 4 * (s & 3) + lk)];
     }
     __syncthreads();
+#if JOSEPH_STOP == 1
+    { double z = 0; if (active) for (int s = 0; s < 4 * NT; ++s) z += af[s]; if (form == 99) Pb[tid] = z; return; }
+#endif
 
     // ---- phase P: P tiles into LDS ------------------------------------------------------------------------
-    for (int t = wave; t < NT * NT; t += 8) {
-        const int I = t / NT, J = t - I * NT;
-        double* tl = lds + t * 256;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = lk + 4 * r;
-            tl[tsw(row, li)] = Pb[(long long)(16 * I + row) * ldn + 16 * J + li];
+    for (int u = 0; u < PT; ++u) {
+        const int t = wave + 8 * u;
+        if (t < NT * NT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds[t * 256 + tsw(lk + 4 * r, li)] = pre_p[u][r];
         }
     }
     __syncthreads();
+#if JOSEPH_STOP == 2
+    { double z = lds[tid]; if (active) for (int s = 0; s < 4 * NT; ++s) z += af[s]; if (form == 99) Pb[tid] = z; return; }
+#endif
 
     // ---- phase 1: AP(blk, :) = A(blk, :) P -------------------------------------------------------------
     v4d acc[NT];
@@ -136,6 +158,9 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
             for (int r = 0; r < 4; ++r) lds[(blk * NT + J) * 256 + tsw(lk + 4 * r, li)] = acc[J][r];
     }
     __syncthreads();
+#if JOSEPH_STOP == 3
+    { double z = lds[tid]; if (active) for (int s = 0; s < 4 * NT; ++s) z += af[s]; if (form == 99) Pb[tid] = z; return; }
+#endif
 
     if (form == 1) {       // P = (AP + AP^T) / 2
         for (int t = wave; t < NT * NT; t += 8) {
@@ -165,9 +190,11 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
                 if (J + t < NT) o[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[t * NT * 256], af[s], o[t], 0, 0, 0);
         }
     }
+#if JOSEPH_STOP == 4
+    { double z = 0; for (int t = 0; t < NT; ++t) z += o[t][0] + o[t][1] + o[t][2] + o[t][3]; if (form == 99) Pb[tid] = z; return; }
+#endif
     {
         // K R K^T: wavefront w < NT stages tile (w, chunk) of K; the next chunk is in flight during the products
-        const double* rd = fv.rdiag + (long long)b * fv.ldm;
         const double* ksrc = Kb + (long long)(16 * wave + lk) * ldk + li;     // element (lk + 4 r, li) of tile `wave`
         const long long r4 = (long long)4 * ldk;
         const bool loader = wave < NT;
@@ -178,9 +205,10 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
         }
         const int nchunk = ml / 16;
         for (int c = 0; c < nchunk; ++c) {
+            double* kc = kst + (KBUF == 2 ? (c & 1) * NT * 256 : 0);
             if (loader) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) kst[wave * 256 + tsw(lk + 4 * r, li)] = pre[r];
+                for (int r = 0; r < 4; ++r) kc[wave * 256 + tsw(lk + 4 * r, li)] = pre[r];
             }
             __syncthreads();
             if (loader && c + 1 < nchunk) {
@@ -191,17 +219,20 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int off = tsw(li, 4 * s + lk);
-                    const double k0 = kst[J * 256 + off];
-                    const double bq = k0 * rd[16 * c + 4 * s + lk];
+                    const double k0 = kc[J * 256 + off];
+                    const double bq = k0 * rds[16 * c + 4 * s + lk];
                     o[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(k0, bq, o[0], 0, 0, 0);
 #pragma unroll
                     for (int t = 1; t < NT; ++t)
-                        if (J + t < NT) o[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kst[(J + t) * 256 + off], bq, o[t], 0, 0, 0);
+                        if (J + t < NT) o[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kc[(J + t) * 256 + off], bq, o[t], 0, 0, 0);
                 }
             }
-            __syncthreads();
+            if (KBUF == 1) __syncthreads();      // with two buffers the next store goes to the other one
         }
     }
+#if JOSEPH_STOP == 5
+    { double z = 0; for (int t = 0; t < NT; ++t) z += o[t][0] + o[t][1] + o[t][2] + o[t][3]; if (form == 99) Pb[tid] = z; return; }
+#endif
     if (!active) return;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {

@@ -312,7 +312,7 @@ bool use_fused_solver(int nl, int ml) { return nl <= 16 * SOLVER_MAX_NT && ml <=
 template <int MT>
 int launch_gain_solver(slamk_handle* h, int nl, double* Lout, hipStream_t st)
 {
-    const size_t lds = ((size_t)MT * (MT + 1) / 2 * 256 + 16) * sizeof(double);
+    const size_t lds = ((size_t)MT * (MT + 1) / 2 * 256 + 256) * sizeof(double);
     static bool attr_done = false;
     if (!attr_done) {
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(gain_solver_kernel<MT>),
@@ -349,7 +349,7 @@ int run_gain_solver(slamk_handle* h, int nl, int ml, hipStream_t st)
 template <int NT>
 int launch_joseph(slamk_handle* h, int ml, hipStream_t st)
 {
-    const size_t lds = (size_t)(NT * NT + NT) * 256 * sizeof(double);
+    const size_t lds = (size_t)(NT * NT + (NT <= 7 ? 2 : 1) * NT + 1) * 256 * sizeof(double);
     static bool attr_done = false;
     if (!attr_done) {
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(joseph_kernel<NT>),
