@@ -30,12 +30,14 @@ int main()
     fv.P = dev(P, B); fv.ha = dev(ha, B); fv.hb = dev(hb, B); fv.rdiag = dev(rd, B);
     fv.rowoff = dev(rowoff, B); fv.isref = dev(isref, B); fv.nf = dev(nfv, B);
     double* Kd = dev(K, B);
-    const size_t lds = (size_t)(NT * NT + (NT <= 7 ? 2 : 1) * NT + 1) * 256 * 8;
+    fv.e = dev(rd, B);
+    double* dxd; hipMalloc(&dxd, (size_t)B * ldn * 8);
+    const size_t lds = (size_t)(NT * NT + (NT <= 7 ? 2 : 1) * NT + 2) * 256 * 8;
     hipFuncSetAttribute(reinterpret_cast<const void*>(joseph_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        joseph_kernel<NT><<<B, 512, lds>>>(fv, Kd, ldm, (long long)ldn * ldm, ml, 0);
+        joseph_kernel<NT><<<B, 512, lds>>>(fv, Kd, ldm, (long long)ldn * ldm, ml, 0, dxd);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("%s: %.3f ms\n", VARIANT, ms);

@@ -1,19 +1,21 @@
 // Fused gain solver for small filters: K = W S^-1 (and K R) from S = L L^T, one workgroup per filter.
 //
-//   in : S  m x m (lower 16-tiles valid), W  n x m,  r[m] (diagonal of R)
+//   in : W = P H^T  n x m, the compact rows of H, r[m] (diagonal of R); S = H W + R is formed in LDS
 //   out: K  n x m, optionally KR = K diag(r) and L (lower)
 //   m = 16 MT with MT <= 11 (the lower tiles of S, 2 KB each, live in LDS: MT (MT+1) / 2 <= 66 tiles),
 //   n = 16 NT with NT <= 8 (one wavefront per 16 columns of W^T).
 //
-// Phase 1  tile Cholesky, right-looking, in LDS.  Per tile column j: wavefront 0 factors the diagonal
-//          tile and replaces it by its inverse; the tiles below become S_ij inv(L_jj)^T; the trailing
-//          tiles take S_ik -= L_ij L_kj^T.  All tile products are v_mfma_f64_16x16x4_f64.
-// Phase 2  two triangular solves on the transposed system, so that finished tiles are consumed
-//          straight from the accumulator registers: an MFMA result tile (lane = column, register =
-//          row group) IS the B operand of the next MFMA, no data movement.
-//            Y^T_j = inv(L_jj)   (W^T_j - sum_{k<j} L_jk   Y^T_k)      j = 0 .. MT-1
+// Tile Cholesky, right-looking, in LDS.  Per tile column j: wavefront 0 factors the diagonal tile and
+//   replaces it by its inverse; the tiles below become S_ij inv(L_jj)^T; the trailing tiles take
+//   S_ik -= L_ij L_kj^T, column j + 1 first so that wavefront 0 can factor the next diagonal tile while the
+//   other wavefronts finish the trailing update and advance the forward solve.  All tile products are
+//   v_mfma_f64_16x16x4_f64.
+// Two triangular solves on the transposed system, so that finished tiles are consumed straight from the
+//   accumulator registers: an MFMA result tile (lane = column, register = row group) IS the B operand of
+//   the next MFMA, no data movement.
+//            Y^T_j = inv(L_jj)   (W^T_j - sum_{k<j} L_jk   Y^T_k)      j = 0 .. MT-1   (beside the factorisation)
 //            K^T_j = inv(L_jj)^T (Y^T_j - sum_{k>j} L_kj^T K^T_k)      j = MT-1 .. 0
-//          Wavefront w owns columns [16 w, 16 w + 16) of W^T / K^T (rows of W / K).
+//   Each of wavefronts 1..7 (and 0 for an eighth block) owns 16 rows of W / K.
 //
 // LDS tile image: element (r, c) of a 16 x 16 tile at r * 16 + (c ^ (r & 14)).  With that XOR every
 // access pattern used here -- row-fragment reads (lane = row, 4 s + kk = column), the same on the
@@ -22,6 +24,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "feature_kernels.hip.h"
 #include "gemm.hip.h"
 
 namespace slamk {
@@ -118,7 +121,7 @@ __device__ __forceinline__ void inv4(const double* l, const double* id, double* 
 //     X_bc = -(sum_{c < k <= b} X_bk L_kc) inv(L_cc),
 // again one LDS round trip per block column.  No divergent branches: lanes that own nothing in a step
 // keep their values through selects.
-__device__ inline void diag_tile_factor_invert(double* t, double* xs, double* __restrict__ Lg, int ldl, int lane)
+__device__ __forceinline__ void diag_tile_factor_invert(double* t, double* xs, double* __restrict__ Lg, int ldl, int lane)
 {
     const int r = lane & 15, cg = lane >> 4, b = r >> 2, i = r & 3;
     double cur[4], idall[16];
@@ -213,41 +216,68 @@ __device__ inline void diag_tile_factor_invert(double* t, double* xs, double* __
 }
 
 template <int MT>
-__global__ void __launch_bounds__(512) gain_solver_kernel(const double* __restrict__ S, const double* __restrict__ W,
-                                                           const double* __restrict__ rdiag, double* __restrict__ K,
-                                                           double* __restrict__ KR, double* __restrict__ L, int ldm,
-                                                           long long sM, long long sNM, int NT)
+__global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, const double* __restrict__ W,
+                                                           double* __restrict__ K, double* __restrict__ KR,
+                                                           double* __restrict__ L, long long sM, long long sNM, int NT)
 {
-    extern __shared__ double lds[];                     // MT (MT + 1) / 2 tiles of 256 doubles + one scratch tile
+    extern __shared__ double lds[];                     // MT (MT + 1) / 2 tiles of 256 doubles + 9 scratch tiles
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const double* Sb = S + (long long)b * sM;
+    const int ldm = fv.ldm;
     double* Lb = L ? L + (long long)b * sM : nullptr;
     constexpr int NTILES = MT * (MT + 1) / 2;
+    constexpr int M = 16 * MT;
+    // Wavefront 0 factors the diagonal tiles; wavefronts 1..7 own row blocks 0..6 of W / K (wavefront 0 takes
+    // block 7 when there is one), so the solves run beside the factorisation.
+    const int blk = (wave + 7) & 7;
+    const bool has_blk = blk < NT;
+    double* stg = lds + (NTILES + 1 + wave) * 256;      // per-wavefront staging tile
+    const double* Wf = W + (long long)b * sNM;
+    const double* rd = fv.rdiag + (long long)b * ldm;
 
-    // ---- load the lower tiles of S (accumulator-shaped: lanes along columns) -------------------
-    for (int t = wave; t < NTILES; t += 8) {
-        int i = 0;
-        while ((i + 1) * (i + 2) / 2 <= t) ++i;
-        const int j = t - i * (i + 1) / 2;
-        double* tl = lds + t * 256;
+    // ---- S = H W + R (calcK, src/slam/main.cpp:541-543), lower tiles, straight into LDS --------------------
+    // Row q of H has entries on columns 0..2 and cs_q..cs_q+2 only, so S[q][q'] is six products with rows of W.
+    // The compact rows of H are staged in the (still unused) staging tiles first.
+    {
+        double* cha = lds + (NTILES + 1) * 256;          // [M][3]
+        double* chb = cha + 3 * M;                       // [M][3]
+        double* crd = chb + 3 * M;                       // [M]
+        int* ccs = reinterpret_cast<int*>(crd + M);      // [M]
+        const long long rb = (long long)b * ldm;
+        for (int t = tid; t < 3 * M; t += 512) { cha[t] = fv.ha[rb * 3 + t]; chb[t] = fv.hb[rb * 3 + t]; }
+        for (int t = tid; t < M; t += 512) { crd[t] = rd[t]; ccs[t] = fv.hcs[rb + t]; }
+        __syncthreads();
+        for (int t = wave; t < NTILES; t += 8) {
+            int i = 0;
+            while ((i + 1) * (i + 2) / 2 <= t) ++i;
+            const int j = t - i * (i + 1) / 2;
+            double* tl = lds + t * 256;
+            const int qc = 16 * j + li;
+            const double x0 = Wf[qc], x1 = Wf[ldm + qc], x2 = Wf[2 * ldm + qc];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = lk + 4 * r;
-            tl[tsw(row, li)] = Sb[(long long)(16 * i + row) * ldm + 16 * j + li];
+            for (int r = 0; r < 4; ++r) {
+                const int row = lk + 4 * r, q = 16 * i + row;
+                const int cs = max(ccs[q], 0);
+                const double* wr = Wf + (long long)cs * ldm + qc;
+                double v = cha[3 * q] * x0;
+                v = fma(cha[3 * q + 1], x1, v);
+                v = fma(cha[3 * q + 2], x2, v);
+                v = fma(chb[3 * q], wr[0], v);
+                v = fma(chb[3 * q + 1], wr[ldm], v);
+                v = fma(chb[3 * q + 2], wr[2 * ldm], v);
+                if (q == qc) v += crd[q];
+                tl[tsw(row, li)] = v;
+            }
         }
     }
 
-    // ---- phase 1: tile Cholesky ---------------------------------------------------------------------
-    for (int j = 0; j < MT; ++j) {
-        __syncthreads();
-        double* tjj = lds + tile_index(j, j) * 256;
-#ifndef SOLVER_ABLATE_DIAG
-        if (wave == 0) diag_tile_factor_invert(tjj, lds + NTILES * 256, Lb ? Lb + (long long)(16 * j) * ldm + 16 * j : nullptr, ldm, lane);
+    // shared steps of tile column j, executed by all eight wavefronts
+    auto panel = [&](int j) {                            // L_ij = S_ij inv(L_jj)^T
+#ifdef SOLVER_ABLATE_PANEL
+        return;
 #endif
-        __syncthreads();
-        // panel: L_ij = S_ij inv(L_jj)^T
+        const double* tjj = lds + tile_index(j, j) * 256;
         for (int i = j + 1 + wave; i < MT; i += 8) {
             double* tij = lds + tile_index(i, j) * 256;
             v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -255,28 +285,114 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(const double* __restri
 #pragma unroll
             for (int r = 0; r < 4; ++r) tij[tsw(lk + 4 * r, li)] = acc[r];
         }
-        __syncthreads();
-        // trailing update: S_ik -= L_ij L_kj^T for j < k <= i
-#ifdef SOLVER_ABLATE_TRAIL
-        const int w = 0;
-#else
-        const int w = MT - j - 1;
+    };
+    auto trail = [&](int i, int k, int j) {              // S_ik -= L_ij L_kj^T
+        double* tik = lds + tile_index(i, k) * 256;
+        v4d acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = tik[tsw(lk + 4 * r, li)];
+        acc = tile_mma_ldsBt<true>(lds + tile_index(i, j) * 256, lds + tile_index(k, j) * 256, acc, li, lk);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tik[tsw(lk + 4 * r, li)] = acc[r];
+    };
+    auto next_column = [&](int j) {                      // column j + 1 of the trailing update first
+#ifdef SOLVER_ABLATE_PANEL
+        return;
 #endif
-        for (int t = wave; t < w * (w + 1) / 2; t += 8) {
-            int ii = 0;
-            while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
-            const int kk = t - ii * (ii + 1) / 2;
-            const int i = j + 1 + ii, k = j + 1 + kk;
-            double* tik = lds + tile_index(i, k) * 256;
-            v4d acc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = tik[tsw(lk + 4 * r, li)];
-            acc = tile_mma_ldsBt<true>(lds + tile_index(i, j) * 256, lds + tile_index(k, j) * 256, acc, li, lk);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) tik[tsw(lk + 4 * r, li)] = acc[r];
-        }
-    }
+        if (j + 1 < MT)
+            for (int i = j + 1 + wave; i < MT; i += 8) trail(i, j + 1, j);
+    };
+
+    v4d y[MT];
     __syncthreads();
+    if (wave == 0) {
+        // ---- wavefront 0: the diagonal tiles, one column ahead of the trailing update ---------------------
+        diag_tile_factor_invert(lds, lds + NTILES * 256, Lb, ldm, lane);
+        for (int j = 0; j < MT; ++j) {
+            __syncthreads();                             // inv(L_jj) is in place
+            panel(j);
+            __syncthreads();
+            next_column(j);
+            __syncthreads();
+#ifndef SOLVER_ABLATE_DIAG
+            if (j + 1 < MT)
+#else
+            if (false)
+#endif
+                diag_tile_factor_invert(lds + tile_index(j + 1, j + 1) * 256, lds + NTILES * 256,
+                                        Lb ? Lb + (long long)(16 * (j + 1)) * ldm + 16 * (j + 1) : nullptr, ldm, lane);
+        }
+        __syncthreads();
+        if (has_blk) {                                   // an eighth row block: its forward solve runs here
+            const double* Wb = W + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li;
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                v4d acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stg[tsw(lk + 4 * r, li)] = Wb[(long long)(4 * r) * ldm + 16 * j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = stg[tsw(li, lk + 4 * r)];
+#pragma unroll
+                for (int k = 0; k < j; ++k) acc = tile_mma_regB<false, true>(lds + tile_index(j, k) * 256, y[k], acc, li, lk);
+                y[j] = tile_mma_regB<false, false>(lds + tile_index(j, j) * 256, acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
+            }
+        }
+    } else {
+        // ---- wavefronts 1..7: rest of the trailing update and Y^T = inv(L) W^T beside the factorisation ------
+        //   Y^T_j = inv(L_jj) (W^T_j - sum_{k<j} L_jk Y^T_k): a finished tile, lane = column, register = row
+        //   group, IS the B operand of the next MFMA.
+        {
+            // tile (blk, j) of W: rows read as 128-byte runs, transposed through the wavefront's staging tile
+            const double* Wb = W + (long long)b * sNM + (long long)(16 * (has_blk ? blk : 0) + lk) * ldm + li;
+            double g[MT][4];
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[j][r] = Wb[(long long)(4 * r) * ldm + 16 * j];
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stg[tsw(lk + 4 * r, li)] = g[j][r];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[j][r] = stg[tsw(li, lk + 4 * r)];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            __syncthreads();
+            panel(j);
+            __syncthreads();
+            next_column(j);
+            __syncthreads();
+#ifndef SOLVER_ABLATE_TRAIL
+            const int w = MT - j - 2;
+#else
+            const int w = 0;
+#endif
+#ifdef SOLVER_ABLATE_W4
+            if (wave != 4)
+#endif
+            for (int t = wave - 1; t < w * (w + 1) / 2; t += 7) {
+                int ii = 0;
+                while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+                const int kk = t - ii * (ii + 1) / 2;
+                trail(j + 2 + ii, j + 2 + kk, j);
+            }
+#ifdef SOLVER_ABLATE_W4
+            if (has_blk && wave != 4) {
+#elif !defined(SOLVER_ABLATE_FWD)
+            if (has_blk) {                               // forward-solve step j
+#else
+            if (false) {
+#endif
+                v4d acc = y[j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) acc = tile_mma_regB<false, true>(lds + tile_index(j, k) * 256, y[k], acc, li, lk);
+                y[j] = tile_mma_regB<false, false>(lds + tile_index(j, j) * 256, acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
+            }
+        }
+        __syncthreads();
+    }
     if (Lb) {   // off-diagonal tiles of L (the diagonal ones were written while they were still L)
         for (int t = wave; t < NTILES; t += 8) {
             int i = 0;
@@ -292,22 +408,9 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(const double* __restri
         }
     }
 
-    // ---- phase 2: K^T = L^-T L^-1 W^T, wavefront w owns rows [16 w, 16 w + 16) of W / K -------------
-#ifdef SOLVER_ABLATE_TRSM
-    return;
-#endif
-    if (wave >= NT) return;
-    const double* Wb = W + (long long)b * sNM + (long long)(16 * wave + li) * ldm;   // row 16 w + li of W
-    v4d y[MT];
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        v4d acc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = Wb[16 * j + lk + 4 * r];                  // W^T tile j, accumulator-shaped
-#pragma unroll
-        for (int k = 0; k < j; ++k) acc = tile_mma_regB<false, true>(lds + tile_index(j, k) * 256, y[k], acc, li, lk);
-        y[j] = tile_mma_regB<false, false>(lds + tile_index(j, j) * 256, acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
-    }
+    // ---- K^T_j = inv(L_jj)^T (Y^T_j - sum_{k>j} L_kj^T K^T_k),  j = MT-1 .. 0 -----------------------------
+    if (!has_blk) return;
+#ifndef SOLVER_ABLATE_BWD
 #pragma unroll
     for (int j = MT - 1; j >= 0; --j) {
         v4d acc = y[j];
@@ -315,17 +418,21 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(const double* __restri
         for (int k = j + 1; k < MT; ++k) acc = tile_mma_regB<true, true>(lds + tile_index(k, j) * 256, y[k], acc, li, lk);
         y[j] = tile_mma_regB<true, false>(lds + tile_index(j, j) * 256, acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
     }
-    double* Kb = K + (long long)b * sNM + (long long)(16 * wave + li) * ldm;
-    double* KRb = KR ? KR + (long long)b * sNM + (long long)(16 * wave + li) * ldm : nullptr;
-    const double* rd = rdiag + (long long)b * ldm;
+#endif
+    // K tiles leave through the staging tile as well: 128-byte runs per row
+    double* Kb = K + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li;
+    double* KRb = KR ? KR + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li : nullptr;
 #pragma unroll
-    for (int j = 0; j < MT; ++j)
+    for (int j = 0; j < MT; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stg[tsw(li, lk + 4 * r)] = y[j][r];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int q = 16 * j + lk + 4 * r;
-            Kb[q] = y[j][r];
-            if (KRb) KRb[q] = y[j][r] * rd[q];
+            const double v = stg[tsw(lk + 4 * r, li)];
+            Kb[(long long)(4 * r) * ldm + 16 * j] = v;
+            if (KRb) KRb[(long long)(4 * r) * ldm + 16 * j] = v * rd[16 * j + li];
         }
+    }
 }
 
 }  // namespace slamk

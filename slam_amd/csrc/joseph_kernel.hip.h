@@ -5,7 +5,7 @@
 // held in registers, K R is never formed in memory: HBM traffic is one read and one write of P plus two
 // reads of K.
 //
-//   phase A  A = I - K H into LDS.  H is sparse: column 6 + 3 i + c of K H only sums the 4 or 6 measurement
+//   phase A  A = I - K H into LDS, and dx = K e (src/slam/main.cpp:228) from the same reads of K.  H is sparse: column 6 + 3 i + c of K H only sums the 4 or 6 measurement
 //            rows of feature i (one lane per feature, rows of K read as contiguous runs), columns 0..2 sum
 //            all rows (lanes along the row of K), the rest of A is I.  Wavefront `blk` then takes its 16
 //            rows of A in MFMA operand layout (lane (li, lk) holds A[16 blk + li][4 s + lk]).
@@ -31,12 +31,13 @@ namespace slamk {
 
 template <int NT>
 __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double* __restrict__ K, int ldk,
-                                                      long long sK, int ml, int form)
+                                                      long long sK, int ml, int form, double* __restrict__ dx)
 {
     extern __shared__ double lds[];                     // NT * NT tiles of 256 doubles (tile (I, J) at I * NT + J)
     constexpr int KBUF = (NT <= 7) ? 2 : 1;             // chunk buffers of K (LDS holds two up to NT = 7)
     double* kst = lds + NT * NT * 256;                  // + KBUF * NT tiles: 16-column chunks of K
     double* rds = kst + KBUF * NT * 256;                // + 256: diagonal of R
+    double* dxs = rds + 256;                            // + 128: dx = K e
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -62,6 +63,7 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
     // ---- phase A: A = I - K H in LDS -------------------------------------------------------------------
     for (int t = tid; t < NT * NT * 256; t += 512) lds[t] = 0.0;
     for (int t = tid; t < ml; t += 512) rds[t] = fv.rdiag[(long long)b * fv.ldm + t];
+    if (tid < 16 * NT) dxs[tid] = 0.0;
     __syncthreads();
     if (tid < 16 * NT) lds[((tid >> 4) * (NT + 1)) * 256 + tsw(tid & 15, tid & 15)] = 1.0;
     __syncthreads();
@@ -85,6 +87,11 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
             }
             const bool alt = (i == 0);
             const double g0 = alt ? ha[0] : 0.0, g1 = alt ? ha[1] : 0.0, g2 = alt ? ha[2] : 0.0;
+            const double* ev = fv.e + (long long)b * fv.ldm;
+            const double e0 = alt ? ev[0] : 0.0;
+            double ef[6];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) ef[t] = (live && (t < 4 || six)) ? ev[row0 + t] : 0.0;
             const int l0 = 6 + 3 * i;
 #pragma unroll
             for (int pass = 0; pass < NT; ++pass) {
@@ -95,6 +102,9 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
                 for (int t = 0; t < 6; ++t) k[t] = (live && (t < 4 || six)) ? kr[row0 + t] : 0.0;
                 const double ka = alt ? kr[0] : 0.0;
                 double x[3] = {ka * g0, ka * g1, ka * g2};
+                double de = ka * e0;                     // this lane's share of dx_j = sum_q K[j][q] e[q]   (main.cpp:228)
+#pragma unroll
+                for (int t = 0; t < 6; ++t) de = fma(k[t], ef[t], de);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     double v = k[0] * h[c];
@@ -108,12 +118,15 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
 #pragma unroll
                 for (int o = 16; o > 0; o >>= 1) {
                     x[0] += __shfl_xor(x[0], o); x[1] += __shfl_xor(x[1], o); x[2] += __shfl_xor(x[2], o);
+                    de += __shfl_xor(de, o);
                 }
+                if (l32 == 3) dxs[j] += de;
                 if (l32 < 3) lds[((j >> 4) * NT) * 256 + tsw(j & 15, l32)] -= (l32 == 0 ? x[0] : (l32 == 1 ? x[1] : x[2]));
             }
         }
     }
     __syncthreads();
+    if (dx && tid < 16 * NT) dx[(long long)b * ldn + tid] = dxs[tid];
     double af[4 * NT];
     if (active) {
 #pragma unroll

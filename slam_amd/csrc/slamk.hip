@@ -312,7 +312,7 @@ bool use_fused_solver(int nl, int ml) { return nl <= 16 * SOLVER_MAX_NT && ml <=
 template <int MT>
 int launch_gain_solver(slamk_handle* h, int nl, double* Lout, hipStream_t st)
 {
-    const size_t lds = ((size_t)MT * (MT + 1) / 2 * 256 + 256) * sizeof(double);
+    const size_t lds = ((size_t)MT * (MT + 1) / 2 * 256 + 9 * 256) * sizeof(double);
     static bool attr_done = false;
     if (!attr_done) {
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(gain_solver_kernel<MT>),
@@ -320,8 +320,8 @@ int launch_gain_solver(slamk_handle* h, int nl, double* Lout, hipStream_t st)
         attr_done = true;
     }
     const long long sM = (long long)h->ldm * h->ldm, sNM = (long long)h->ldn * h->ldm;
-    hipLaunchKernelGGL(gain_solver_kernel<MT>, dim3(h->B), dim3(512), lds, st, h->S, h->W, h->fv.rdiag, h->K,
-                       (double*)nullptr, Lout, h->ldm, sM, sNM, nl / 16);
+    hipLaunchKernelGGL(gain_solver_kernel<MT>, dim3(h->B), dim3(512), lds, st, h->fv, h->W, h->K, (double*)nullptr, Lout,
+                       sM, sNM, nl / 16);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -349,7 +349,7 @@ int run_gain_solver(slamk_handle* h, int nl, int ml, hipStream_t st)
 template <int NT>
 int launch_joseph(slamk_handle* h, int ml, hipStream_t st)
 {
-    const size_t lds = (size_t)(NT * NT + (NT <= 7 ? 2 : 1) * NT + 1) * 256 * sizeof(double);
+    const size_t lds = (size_t)(NT * NT + (NT <= 7 ? 2 : 1) * NT + 2) * 256 * sizeof(double);
     static bool attr_done = false;
     if (!attr_done) {
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(joseph_kernel<NT>),
@@ -357,7 +357,7 @@ int launch_joseph(slamk_handle* h, int ml, hipStream_t st)
         attr_done = true;
     }
     hipLaunchKernelGGL(joseph_kernel<NT>, dim3(h->B), dim3(512), lds, st, h->fv, h->K, h->ldm,
-                       (long long)h->ldn * h->ldm, ml, h->prm.update_form);
+                       (long long)h->ldn * h->ldm, ml, h->prm.update_form, h->dx);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -403,8 +403,9 @@ int run_update(slamk_handle* h, const double* qbw, const double* alt, const doub
     ProfScope ps(h, PC_STRUCT_GAIN, st);
     // W = P H^T                                  (calcK, src/slam/main.cpp:545)
     launch_right(MH, h->fv.P, ldn, sN, h->W, ldm, sNM, nl, ml, B, st);
-    // S = H W + R, lower part                    (:541-543)
-    launch_left<true>(MH, h->W, ldm, sNM, h->S, ldm, sM, h->fv.rdiag, ldm, ml, ml, B, st);
+    // S = H W + R, lower part                    (:541-543); the fused solver forms it in LDS itself
+    if (!use_fused_solver(nl, ml))
+        launch_left<true>(MH, h->W, ldm, sNM, h->S, ldm, sM, h->fv.rdiag, ldm, ml, ml, B, st);
     }
     if (use_fused_solver(nl, ml)) {
         // small filters: S = L L^T and K = W L^-T L^-1 (plus K R) in one workgroup per filter
@@ -463,7 +464,8 @@ int run_update(slamk_handle* h, const double* qbw, const double* alt, const doub
     }
     ProfScope ps_tail(h, PC_FEATURE, st);
     // dx = K e, gate, mean update                (main.cpp:228-232)
-    hipLaunchKernelGGL(gain_kx_kernel, dim3((nl + 15) / 16, B), dim3(256), 0, st, h->fv, h->K, ldm, h->dx, ml);
+    if (!use_fused_solver(nl, ml))      // the fused covariance update has already formed dx
+        hipLaunchKernelGGL(gain_kx_kernel, dim3((nl + 15) / 16, B), dim3(256), 0, st, h->fv, h->K, ldm, h->dx, ml);
     hipLaunchKernelGGL(gain_apply_kernel, dim3(B), dim3(256), 0, st, h->fv, h->dx, applied);
     HIPCHK(h, hipGetLastError());
     return 0;
