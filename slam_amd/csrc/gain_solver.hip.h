@@ -272,19 +272,12 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, const d
         }
     }
 
-    // shared steps of tile column j, executed by all eight wavefronts
-    auto panel = [&](int j) {                            // L_ij = S_ij inv(L_jj)^T
-#ifdef SOLVER_ABLATE_PANEL
-        return;
-#endif
-        const double* tjj = lds + tile_index(j, j) * 256;
-        for (int i = j + 1 + wave; i < MT; i += 8) {
-            double* tij = lds + tile_index(i, j) * 256;
-            v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-            acc = tile_mma_ldsBt<false>(tij, tjj, acc, li, lk);
+    auto panel_tile = [&](int i, int j) {                // L_ij = S_ij inv(L_jj)^T
+        double* tij = lds + tile_index(i, j) * 256;
+        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+        acc = tile_mma_ldsBt<false>(tij, lds + tile_index(j, j) * 256, acc, li, lk);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tij[tsw(lk + 4 * r, li)] = acc[r];
-        }
+        for (int r = 0; r < 4; ++r) tij[tsw(lk + 4 * r, li)] = acc[r];
     };
     auto trail = [&](int i, int k, int j) {              // S_ik -= L_ij L_kj^T
         double* tik = lds + tile_index(i, k) * 256;
@@ -295,32 +288,25 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, const d
 #pragma unroll
         for (int r = 0; r < 4; ++r) tik[tsw(lk + 4 * r, li)] = acc[r];
     };
-    auto next_column = [&](int j) {                      // column j + 1 of the trailing update first
-#ifdef SOLVER_ABLATE_PANEL
-        return;
-#endif
-        if (j + 1 < MT)
-            for (int i = j + 1 + wave; i < MT; i += 8) trail(i, j + 1, j);
-    };
 
+    // Per tile column j, two barriers:  A  inv(L_jj) is in place and step j - 1 is complete;
+    //                                   B  the panel tiles L_ij are final.
     v4d y[MT];
     __syncthreads();
     if (wave == 0) {
-        // ---- wavefront 0: the diagonal tiles, one column ahead of the trailing update ---------------------
+        // ---- wavefront 0: the chain  L_j+1,j -> S_j+1,j+1 -> factor -> inverse  of the next diagonal tile ----
         diag_tile_factor_invert(lds, lds + NTILES * 256, Lb, ldm, lane);
         for (int j = 0; j < MT; ++j) {
-            __syncthreads();                             // inv(L_jj) is in place
-            panel(j);
-            __syncthreads();
-            next_column(j);
-            __syncthreads();
+            __syncthreads();                             // A
+            if (j + 1 < MT) panel_tile(j + 1, j);
+            __syncthreads();                             // B
+            if (j + 1 < MT) {
+                trail(j + 1, j + 1, j);
 #ifndef SOLVER_ABLATE_DIAG
-            if (j + 1 < MT)
-#else
-            if (false)
-#endif
                 diag_tile_factor_invert(lds + tile_index(j + 1, j + 1) * 256, lds + NTILES * 256,
                                         Lb ? Lb + (long long)(16 * (j + 1)) * ldm + 16 * (j + 1) : nullptr, ldm, lane);
+#endif
+            }
         }
         __syncthreads();
         if (has_blk) {                                   // an eighth row block: its forward solve runs here
@@ -338,7 +324,7 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, const d
             }
         }
     } else {
-        // ---- wavefronts 1..7: rest of the trailing update and Y^T = inv(L) W^T beside the factorisation ------
+        // ---- wavefronts 1..7: panel, trailing update and Y^T = inv(L) W^T beside the factorisation -----------
         //   Y^T_j = inv(L_jj) (W^T_j - sum_{k<j} L_jk Y^T_k): a finished tile, lane = column, register = row
         //   group, IS the B operand of the next MFMA.
         {
@@ -357,30 +343,33 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, const d
                 for (int r = 0; r < 4; ++r) y[j][r] = stg[tsw(li, lk + 4 * r)];
             }
         }
+        const int wk = wave - 1;                         // 0..6
+        // wavefront 4 shares its SIMD with wavefront 0 and takes no part in the bulk of the trailing update
+        const int wk6 = wave < 4 ? wave - 1 : wave - 2;  // 0..5 for wavefronts 1 2 3 5 6 7
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
-            __syncthreads();
-            panel(j);
-            __syncthreads();
-            next_column(j);
-            __syncthreads();
+            __syncthreads();                             // A
+#ifndef SOLVER_ABLATE_PANEL
+            for (int i = j + 2 + wk; i < MT; i += 7) panel_tile(i, j);
+#endif
+            __syncthreads();                             // B
+#ifndef SOLVER_ABLATE_PANEL
+            for (int i = j + 2 + wk; i < MT; i += 7) trail(i, j + 1, j);      // column j + 1 first
+#endif
 #ifndef SOLVER_ABLATE_TRAIL
             const int w = MT - j - 2;
 #else
             const int w = 0;
 #endif
-#ifdef SOLVER_ABLATE_W4
-            if (wave != 4)
-#endif
-            for (int t = wave - 1; t < w * (w + 1) / 2; t += 7) {
-                int ii = 0;
-                while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
-                const int kk = t - ii * (ii + 1) / 2;
-                trail(j + 2 + ii, j + 2 + kk, j);
+            if (wave != 4) {
+                for (int t = wk6; t < w * (w + 1) / 2; t += 6) {
+                    int ii = 0;
+                    while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+                    const int kk = t - ii * (ii + 1) / 2;
+                    trail(j + 2 + ii, j + 2 + kk, j);
+                }
             }
-#ifdef SOLVER_ABLATE_W4
-            if (has_blk && wave != 4) {
-#elif !defined(SOLVER_ABLATE_FWD)
+#if !defined(SOLVER_ABLATE_FWD)
             if (has_blk) {                               // forward-solve step j
 #else
             if (false) {

@@ -207,8 +207,9 @@ constexpr int STRUCT_RPW = 8;        // rows per wavefront in the structured pro
 void launch_right(const RowSparse& M, const double* In, int ldi, long long sIn, double* Out, int ldo, long long sOut,
                   int rows, int cols, int B, hipStream_t st)
 {
-    hipLaunchKernelGGL(rowsparse_right_kernel, dim3((cols + 63) / 64, (rows + 4 * STRUCT_RPW - 1) / (4 * STRUCT_RPW), B),
-                       dim3(256), 0, st, M, In, ldi, sIn, Out, ldo, sOut, rows, cols, STRUCT_RPW);
+    hipLaunchKernelGGL(rowsparse_right_kernel<STRUCT_RPW>,
+                       dim3((cols + 63) / 64, (rows + 4 * STRUCT_RPW - 1) / (4 * STRUCT_RPW), B), dim3(256), 0, st, M, In,
+                       ldi, sIn, Out, ldo, sOut, rows, cols);
 }
 
 template <bool LOWER>
@@ -237,8 +238,7 @@ int run_predict(slamk_handle* h, const double* qbw, const double* w, const doubl
     ProfScope ps(h, PC_STRUCT_PREDICT, st);
     // T = P F^T ; P = F T + Q      (calcP, src/slam/main.cpp:526-530, G = I)
     const int nt = (nl + 2) / 3;
-    hipLaunchKernelGGL(predict_cov_kernel, dim3((nt + 15) / 16, (nt + 15) / 16, B), dim3(256), 0, st, h->fv, h->fv.P,
-                       h->T, nl);
+    hipLaunchKernelGGL(predict_cov_kernel, dim3((nt * nt + 255) / 256, B), dim3(256), 0, st, h->fv, h->fv.P, h->T, nl);
     std::swap(h->fv.P, h->T);          // T is whichever of the two covariance-sized buffers is not P
     HIPCHK(h, hipGetLastError());
     return 0;

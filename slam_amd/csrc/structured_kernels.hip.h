@@ -85,14 +85,15 @@ struct RowSparse {            // row q: ca[q][0..2] on columns c0..c0+2, cb[q][0
 };
 
 // Out[j][q] = sum_k In[j][k] M[q][k]   (In * M^T), M row-sparse with `cols` rows; lanes along q.
-// grid (ceil(cols / 64), ceil(rows / (4 rpw)), B), 256 threads; each wavefront walks rpw rows.
+// grid (ceil(cols / 64), ceil(rows / (4 RPW)), B), 256 threads; each wavefront walks RPW rows.
+template <int RPW>
 __global__ void __launch_bounds__(256) rowsparse_right_kernel(RowSparse M, const double* __restrict__ In, int ldi,
                                                                long long sIn, double* __restrict__ Out, int ldo,
-                                                               long long sOut, int rows, int cols, int rpw)
+                                                               long long sOut, int rows, int cols)
 {
     const int b = blockIdx.z;
     const int q = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int j0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * rpw;
+    const int j0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * RPW;
     if (q >= cols) return;
     const long long cr = (long long)b * M.stride + q;
     const double a0 = M.ca[cr * 3], a1 = M.ca[cr * 3 + 1], a2 = M.ca[cr * 3 + 2];
@@ -106,16 +107,24 @@ __global__ void __launch_bounds__(256) rowsparse_right_kernel(RowSparse M, const
     const double v0 = first ? a0 : b0, v1 = first ? a1 : b1, v2 = first ? a2 : b2;
     const double* Ib = In + (long long)b * sIn;
     double* Ob = Out + (long long)b * sOut;
-    for (int r = 0; r < rpw; ++r) {
+    double x[RPW][6];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {                     // all loads of the wavefront's rows in flight together
+        const int j = min(j0 + r, rows - 1);
+        const double* row = Ib + (long long)j * ldi;
+        x[r][0] = row[k1]; x[r][1] = row[k1 + 1]; x[r][2] = row[k1 + 2];
+        x[r][3] = row[k2]; x[r][4] = row[k2 + 1]; x[r][5] = row[k2 + 2];
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
         const int j = j0 + r;
         if (j >= rows) break;
-        const double* row = Ib + (long long)j * ldi;
-        double acc = row[k1] * u0;
-        acc = fma(row[k1 + 1], u1, acc);
-        acc = fma(row[k1 + 2], u2, acc);
-        acc = fma(row[k2], v0, acc);
-        acc = fma(row[k2 + 1], v1, acc);
-        acc = fma(row[k2 + 2], v2, acc);
+        double acc = x[r][0] * u0;
+        acc = fma(x[r][1], u1, acc);
+        acc = fma(x[r][2], u2, acc);
+        acc = fma(x[r][3], v0, acc);
+        acc = fma(x[r][4], v1, acc);
+        acc = fma(x[r][5], v2, acc);
         Ob[(long long)j * ldo + q] = acc;
     }
 }
@@ -175,15 +184,16 @@ __global__ void __launch_bounds__(256) rowsparse_left_kernel(RowSparse M, const 
 // block (row triple tj, column triple tl) of the output; the three rows (columns) of a triple share
 // their group start, so the block depends on the 6 x 6 entries Pin[{g_j.., 3..5}][{g_l.., 3..5}] only.
 // The inner sums run in ascending index like the two dense products T = P F^T, P = F T would.
-// Pin and Pout must be different buffers.  grid (ceil(nt / 16), ceil(nt / 16), B), nt = ceil(nl / 3); 256 threads.
+// Pin and Pout must be different buffers.  grid (ceil(nt * nt / 256), B), nt = ceil(nl / 3); 256 threads.
 __global__ void __launch_bounds__(256) predict_cov_kernel(FilterView fv, const double* __restrict__ Pin,
                                                            double* __restrict__ Pout, int nl)
 {
-    const int b = blockIdx.z;
-    const int tl = blockIdx.x * 16 + (threadIdx.x & 15);
-    const int tj = blockIdx.y * 16 + (threadIdx.x >> 4);
+    const int b = blockIdx.y;
+    const int nt = (nl + 2) / 3;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int tj = t / nt, tl = t - tj * nt;
     const int j0 = 3 * tj, l0 = 3 * tl;
-    if (j0 >= nl || l0 >= nl) return;
+    if (tj >= nt) return;
     const long long cb = (long long)b * fv.ldn;
     const int ldn = fv.ldn;
     const double* Pb = Pin + cb * ldn;

@@ -71,7 +71,7 @@ def test_dgemm_kernel_against_numpy():
     assert np.array_equal(dC.cpu().numpy(), Bm.T)
 
 
-@pytest.mark.parametrize("nf,form", [(5, 0), (20, 0), (20, 1), (32, 0)])
+@pytest.mark.parametrize("nf,form", [(5, 0), (20, 0), (20, 1), (32, 0), (32, 1)])
 def test_single_filter_stream_parity(nf, form):
     st = synth.gen_stream(seed=10 + nf, nf=nf, steps=61, churn=True, drop_at=21, drop_count=min(3, nf - 1),
                           add_at=42, add_count=3)
@@ -84,6 +84,19 @@ def test_single_filter_stream_parity(nf, form):
     nfs = {len(s["ids"]) for s in sg}
     assert len(nfs) > 1                      # the stream really exercised insert / delete
     print("nf=%d form=%d worst rel err %.2e" % (nf, form, worst))
+
+
+@pytest.mark.parametrize("nf,ref_fraction,form", [(2, 0.5, 0), (38, 0.0, 0), (38, 0.0, 1), (26, 1.0, 0)])
+def test_fused_path_tile_count_edges(nf, ref_fraction, form):
+    """Smallest filter, eight 16-row blocks of the state (n = 123), and all-reflection rows (m = 157)."""
+    st = synth.gen_stream(seed=70 + nf, nf=nf, steps=31, churn=False, ref_fraction=ref_fraction)
+    so, _ = helpers.run_oracle(st)
+    p = ekf.default_params()
+    p.update_form = form
+    fb = ekf.FilterBatch(max_features=nf, batch=1, params=p)
+    sg = helpers.run_gpu(st, fb)
+    worst = compare_snaps(so, sg)
+    print("nf=%d ref=%.1f form=%d worst rel err %.2e" % (nf, ref_fraction, form, worst))
 
 
 def test_per_function_parity():
