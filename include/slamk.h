@@ -181,6 +181,8 @@ int slamk_profile_read(slamk_handle* h, double* ms, int* count, int ncat);
  * fp64-matrix roofline fraction. */
 double slamk_flops_predict(int n);
 double slamk_flops_update(int n, int m, int update_form);
+/* The same split by stage: 0 = gain (factorisation + solves), 1 = covariance update. */
+double slamk_flops_update_stage(int n, int m, int update_form, int stage);
 
 #ifdef __cplusplus
 }

@@ -61,6 +61,7 @@ SIGNATURES = {
     "slamk_profile_read": (C.c_int, [_H, _dp, C.POINTER(C.c_int), C.c_int]),
     "slamk_flops_predict": (C.c_double, [C.c_int]),
     "slamk_flops_update": (C.c_double, [C.c_int, C.c_int, C.c_int]),
+    "slamk_flops_update_stage": (C.c_double, [C.c_int, C.c_int, C.c_int, C.c_int]),
 }
 
 _lib = None

@@ -1039,24 +1039,27 @@ double slamk_flops_predict(int n)
     return 0.0;        // the predict products run on the compact rows of F: no MFMA work
 }
 
-double slamk_flops_update(int n, int m, int update_form)
+double slamk_flops_update_stage(int n, int m, int update_form, int stage)
 {
     const int nl = pad16(n), ml = pad16(m);
     double f = 0;
     if (use_fused_solver(nl, ml)) {
-        // fused solver: 16^3-tile products (2 * 16^3 flop each) of the tile Cholesky and the two solves
+        // 16^3-tile products (2 * 16^3 flop each)
         const int MT = ml / 16, NT = nl / 16;
         double tp = 0;
-        for (int j = 0; j < MT; ++j) {
-            const int w = MT - j - 1;
-            tp += w + w * (w + 1) / 2;
+        if (stage == 0) {          // fused gain solver: tile Cholesky and the two triangular solves
+            for (int j = 0; j < MT; ++j) {
+                const int w = MT - j - 1;
+                tp += w + w * (w + 1) / 2;
+            }
+            tp += 2.0 * NT * (MT * (MT - 1) / 2 + MT);
+        } else {                   // fused covariance update: A P, then the lower tiles of (A P) A^T + K R K^T
+            tp += (double)NT * NT * NT;
+            if (update_form == 0) tp += NT * (NT + 1) / 2 * (double)(NT + MT);
         }
-        tp += 2.0 * NT * (MT * (MT - 1) / 2 + MT);
-        // fused covariance update: A P, then the lower tiles of (A P) A^T + K R K^T
-        tp += (double)NT * NT * NT;
-        if (update_form == 0) tp += NT * (NT + 1) / 2 * (double)(NT + MT);
         return tp * 8192.0;
-    } else {
+    }
+    if (stage == 0) {
         const int NB = (ml <= 1024) ? 64 : 128;
         for (int j0 = 0; j0 < ml; j0 += NB) {
             const int nb = std::min(NB, ml - j0), rem = ml - j0 - nb;
@@ -1071,6 +1074,7 @@ double slamk_flops_update(int n, int m, int update_form)
         }
         f += gemm_flops(nl, ml, ml, false, TRI_B_KLE_N);           // Y
         f += gemm_flops(nl, ml, ml, false, TRI_B_KGE_N);           // K
+        return f;
     }
     f += gemm_flops(nl, nl, nl, false, TRI_NONE);              // A P
     if (update_form == 0) {
@@ -1078,6 +1082,11 @@ double slamk_flops_update(int n, int m, int update_form)
         f += gemm_flops(nl, nl, ml, true, TRI_NONE);           // (K R) K^T, lower tiles
     }
     return f;
+}
+
+double slamk_flops_update(int n, int m, int update_form)
+{
+    return slamk_flops_update_stage(n, m, update_form, 0) + slamk_flops_update_stage(n, m, update_form, 1);
 }
 
 }  // extern "C"

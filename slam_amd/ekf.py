@@ -196,6 +196,11 @@ def flops_update(n, m, update_form=0):
     return _lib.lib().slamk_flops_update(int(n), int(m), int(update_form))
 
 
+def flops_update_stage(n, m, update_form=0, stage=0):
+    """MFMA flops of one update by stage: 0 = gain (factorisation + solves), 1 = covariance update."""
+    return _lib.lib().slamk_flops_update_stage(int(n), int(m), int(update_form), int(stage))
+
+
 def mfma_f64_probe(iters=20000):
     t = C.c_double(0)
     rc = _lib.lib().slamk_mfma_f64_probe(int(iters), C.byref(t))

@@ -34,8 +34,18 @@ def test_default_params_match_reference_constants():
 
 
 def test_flop_model_is_close_to_dense_formula():
-    # executed flops (tile skipping, triangular trimming) stay within the dense Cholesky+Joseph model
-    n, m = 105, 161
-    dense = 8 * n**3 + 6 * n * n * m + 4 * n * m * m + m**3 / 3 + 2 * n * m
-    ex = _lib.lib().slamk_flops_predict(n) + _lib.lib().slamk_flops_update(n, m, 0)
-    assert 0.8 * dense < ex < 1.6 * dense
+    # executed MFMA flops (tile skipping, triangular trimming, padding to 16) against the textbook counts of
+    # what runs on MFMA: Cholesky, the two triangular solves and the Joseph products.  The products with the
+    # sparse Jacobians F and H are not MFMA work.
+    L = _lib.lib()
+    assert L.slamk_flops_predict(105) == 0.0
+    n, m = 105, 161                                   # fused small-filter path
+    model = m**3 / 3 + 2 * n * m * m + 3 * n**3 + n * n * m
+    ex = L.slamk_flops_update(n, m, 0)
+    assert 0.8 * model < ex < 1.6 * model
+    assert ex == L.slamk_flops_update_stage(n, m, 0, 0) + L.slamk_flops_update_stage(n, m, 0, 1)
+    assert L.slamk_flops_update_stage(n, m, 1, 1) < L.slamk_flops_update_stage(n, m, 0, 1)
+    n, m = 6009, 10001                                # blocked large-map path (explicit triangular inverse)
+    model = 2 * m**3 / 3 + 2 * n * m * m + 3 * n**3 + n * n * m
+    ex = L.slamk_flops_update(n, m, 0)
+    assert 0.8 * model < ex < 1.3 * model
