@@ -129,6 +129,20 @@ int slamk_predict_dev(slamk_handle* h, const double* qbw_dev, const double* w_de
                       const double* dt_dev, void* stream);
 int slamk_update_dev(slamk_handle* h, const double* qbw_dev, const double* alt_dev, const double* src_dev,
                      const double* refl_dev, int32_t* applied_dev, void* stream);
+/* One loop iteration with an image for every filter of the batch (src/slam/main.cpp:167-233): frame
+ * begin, predict and update in one call, arguments as for the three calls above.  With
+ * slamk_set_pipeline_groups(h, g), g > 1, the batch is cut into g ranges of filters that run the chain
+ * on internal streams (forked from `stream`, joined into it before the call returns), so kernels of
+ * different ranges overlap; results are identical to the three separate calls. */
+int slamk_step_dev(slamk_handle* h, const double* qbw_dev, const double* w_dev, const double* acc_dev,
+                   const double* dt_dev, const double* alt_dev, const double* src_dev,
+                   const double* refl_dev, int32_t* applied_dev, void* stream);
+int slamk_set_pipeline_groups(slamk_handle* h, int groups);
+/* Graph mode: slamk_step_dev captures its launch sequence into a hipGraph the first time it sees a set of
+ * argument pointers and a feature layout, and replays it afterwards (one submission per iteration instead
+ * of about ten launches: what a single small filter's latency is made of).  `stream` must not be the null
+ * stream; stage timing (slamk_profile_enable) turns graph mode off for the calls it covers. */
+int slamk_set_graph_mode(slamk_handle* h, int on);
 /* Waits for `stream` and returns SLAMK_EREFL / SLAMK_OK from the per-filter status words. */
 int slamk_sync(slamk_handle* h, void* stream);
 
@@ -151,6 +165,9 @@ int slamk_buffer_dev(slamk_handle* h, int which, double** ptr, int* rows, int* c
 int slamk_cholesky_inverse_dev(double* S_dev, double* L_dev, double* Li_dev, int m, int ld, void* stream);
 
 /* ---- introspection for tests and benchmarks (no counterpart in the reference) ----------- */
+/* Introspection is opt-in: after slamk_set_debug(h, 1) every predict/update also writes the dense F, H and
+ * the Cholesky factor L, which the products themselves never need. */
+int slamk_set_debug(slamk_handle* h, int on);
 /* Copies of the last update's intermediates of filter b (NULL = skip): H m x n, S's Cholesky
  * factor L m x m (lower), K n x m, innovation e[m]. */
 int slamk_debug_get(slamk_handle* h, int b, double* H, double* L, double* K, double* e);

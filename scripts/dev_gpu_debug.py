@@ -33,6 +33,7 @@ S = H@P@H.T + np.diag(rd)
 Lo = np.linalg.cholesky(S)
 P2 = orc.update_p(P, K, H)
 # gpu
+fb.set_debug(True)
 fb.frame(0, matches, quat)
 fb.predict(quat, ang, acc, [dt])
 Pg = fb.get_cov(0)

@@ -46,12 +46,16 @@ SIGNATURES = {
     "slamk_frame_begin_dev": (C.c_int, [_H, _vp]),
     "slamk_predict_dev": (C.c_int, [_H, _vp, _vp, _vp, _vp, _vp]),
     "slamk_update_dev": (C.c_int, [_H, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "slamk_step_dev": (C.c_int, [C.c_void_p] * 10),
+    "slamk_set_pipeline_groups": (C.c_int, [C.c_void_p, C.c_int]),
+    "slamk_set_graph_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "slamk_sync": (C.c_int, [_H, _vp]),
     "slamk_stage_motion_dev": (C.c_int, [_H, _vp, _vp, _vp, _vp, _vp]),
     "slamk_stage_measure_dev": (C.c_int, [_H, _vp, _vp, _vp, _vp, _vp]),
     "slamk_stage_apply_dev": (C.c_int, [_H, _vp, C.c_int, _vp, _vp]),
     "slamk_buffer_dev": (C.c_int, [_H, C.c_int, C.POINTER(_vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "slamk_cholesky_inverse_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "slamk_set_debug": (C.c_int, [C.c_void_p, C.c_int]),
     "slamk_debug_get": (C.c_int, [_H, C.c_int, _vp, _vp, _vp, _vp]),
     "slamk_debug_get_F": (C.c_int, [_H, C.c_int, _vp]),
     "slamk_dgemm_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int, C.c_longlong,

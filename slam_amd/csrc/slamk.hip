@@ -59,6 +59,20 @@ struct slamk_handle {
     std::string err;
     hipStream_t stream = nullptr;
     int last_nl = 0, last_ml = 0;
+    // slamk_step_dev: ranges of the batch on streams of their own
+    int groups = 1;
+    std::vector<hipStream_t> gstreams;
+    std::vector<hipEvent_t> gdone;
+    hipEvent_t fork = nullptr;
+    // slamk_step_dev in graph mode: captured launch sequences, keyed by everything baked into the launches
+    bool debug = false;                    // materialise dense F, H and L for slamk_debug_get*
+    bool graph_mode = false;
+    struct GraphKey {
+        const void* p[8]; const double* P; int nl, ml, nfmax, form;
+        bool operator==(const GraphKey& o) const { return memcmp(this, &o, sizeof *this) == 0; }
+    };
+    struct GraphEntry { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;
     // optional per-stage timing with HIP events on the launch stream (slamk_profile_*)
     bool prof_on = false;
     struct ProfRec { int cat; hipEvent_t a, b; };
@@ -200,7 +214,7 @@ __global__ void init_cov_kernel(double* P, int ld, long long stride, double pini
 // covariance pipelines (all launches on one stream, no host synchronisation)
 // ------------------------------------------------------------------------------------------------
 // dense F and H are only materialised for introspection (slamk_debug_get*), never for the products
-bool keep_dense(const slamk_handle* h, int nl) { return h->B <= 64 && nl <= 512; }
+bool keep_dense(const slamk_handle* h, int nl) { (void)nl; return h->debug; }
 
 constexpr int STRUCT_RPW = 8;        // rows per wavefront in the structured product kernels
 
@@ -221,27 +235,65 @@ void launch_left(const RowSparse& M, const double* In, int ldi, long long sIn, d
                        ldi, sIn, Out, ldo, sOut, diag, sDiag, rows, cols, STRUCT_RPW);
 }
 
-int run_predict(slamk_handle* h, const double* qbw, const double* w, const double* acc, const double* dt,
-                hipStream_t st)
+// A contiguous range of the filters of a handle: the device view and the workspaces, offset to its first filter.
+struct Range {
+    FilterView fv;
+    int B;
+    double *T, *W, *K, *KR, *Y, *S, *L, *Li, *Am, *AP, *Hm, *Fm, *dx;
+};
+
+Range make_range(const slamk_handle* h, int b0, int cnt)
 {
-    const int B = h->B, nl = max_nl(h), ldn = h->ldn;
-    const long long sN = (long long)ldn * ldn;
+    Range r;
+    const size_t F = h->F, ldn = h->ldn, ldm = h->ldm, o = b0;
+    r.B = cnt;
+    r.fv = h->fv;
+    FilterView& v = r.fv;
+    v.B = cnt;
+    v.X += 3 * o; v.V += 3 * o; v.bias += 3 * o; v.old_pos += 3 * o;
+    v.nf += o; v.m += o; v.status += o;
+    v.pib += 3 * F * o; v.anchor += 3 * F * o; v.q0 += 4 * F * o; v.pib0 += 2 * F * o;
+    v.isref += F * o; v.rowoff += F * o; v.msrc += 2 * F * o; v.mrefl += 2 * F * o;
+    v.P += ldn * ldn * o;
+    v.ha += 3 * ldm * o; v.hb += 3 * ldm * o; v.hcs += ldm * o;
+    v.e += ldm * o; v.rdiag += ldm * o; v.qdiag += ldn * o;
+    v.fa += 3 * ldn * o; v.fg += 3 * ldn * o; v.fgs += ldn * o;
+    r.T = h->T + ldn * ldn * o; r.Am = h->Am + ldn * ldn * o; r.AP = h->AP + ldn * ldn * o; r.Fm = h->Fm + ldn * ldn * o;
+    r.Hm = h->Hm + ldm * ldn * o;
+    r.W = h->W + ldn * ldm * o; r.K = h->K + ldn * ldm * o; r.KR = h->KR + ldn * ldm * o; r.Y = h->Y + ldn * ldm * o;
+    r.S = h->S + ldm * ldm * o; r.L = h->L + ldm * ldm * o; r.Li = h->Li + ldm * ldm * o;
+    r.dx = h->dx + ldn * o;
+    return r;
+}
+
+int run_predict(slamk_handle* h, const Range& rg, const double* qbw, const double* w, const double* acc,
+                const double* dt, hipStream_t st)
+{
+    // Reads rg.fv.P, leaves the propagated covariance in rg.T: the caller swaps the two buffers of the handle.
+    const int B = rg.B, nl = max_nl(h);
     h->last_nl = nl;
     {
         ProfScope ps(h, PC_FEATURE, st);
-        hipLaunchKernelGGL(motion_rows_kernel, dim3((nl + 255) / 256, B), dim3(256), 0, st, h->fv, qbw, w, dt, nl);
+        hipLaunchKernelGGL(motion_rows_kernel, dim3((nl + 255) / 256, B), dim3(256), 0, st, rg.fv, qbw, w, dt, nl);
         if (keep_dense(h, nl))
-            hipLaunchKernelGGL(build_F_kernel, dim3((nl + 63) / 64, (nl + 3) / 4, B), dim3(256), 0, st, h->fv, qbw, w,
-                               dt, h->Fm, nl);
-        hipLaunchKernelGGL(dynamics_kernel, dim3(B), dim3(256), 0, st, h->fv, qbw, w, acc, dt);
+            hipLaunchKernelGGL(build_F_kernel, dim3((nl + 63) / 64, (nl + 3) / 4, B), dim3(256), 0, st, rg.fv, qbw, w,
+                               dt, rg.Fm, nl);
+        hipLaunchKernelGGL(dynamics_kernel, dim3(B), dim3(256), 0, st, rg.fv, qbw, w, acc, dt);
     }
     ProfScope ps(h, PC_STRUCT_PREDICT, st);
-    // T = P F^T ; P = F T + Q      (calcP, src/slam/main.cpp:526-530, G = I)
+    // P <- F P F^T + Q      (calcP, src/slam/main.cpp:526-530, G = I)
     const int nt = (nl + 2) / 3;
-    hipLaunchKernelGGL(predict_cov_kernel, dim3((nt * nt + 255) / 256, B), dim3(256), 0, st, h->fv, h->fv.P, h->T, nl);
-    std::swap(h->fv.P, h->T);          // T is whichever of the two covariance-sized buffers is not P
+    hipLaunchKernelGGL(predict_cov_kernel, dim3((nt * nt + 255) / 256, B), dim3(256), 0, st, rg.fv, rg.fv.P, rg.T, nl);
     HIPCHK(h, hipGetLastError());
     return 0;
+}
+
+// The range with the roles of P and T exchanged: what the update sees after run_predict on `rg`.
+Range after_predict(const Range& rg)
+{
+    Range r = rg;
+    std::swap(r.fv.P, r.T);
+    return r;
 }
 
 // S (lower) -> L (Cholesky factor) and Li = inv(L); S is used as scratch afterwards.
@@ -300,9 +352,9 @@ int cholesky_inverse(slamk_handle* h, double* Sp, double* Lp, double* Lip, int l
     return 0;
 }
 
-int run_cholesky_inverse(slamk_handle* h, int ml, hipStream_t st)
+int run_cholesky_inverse(slamk_handle* h, const Range& rg, int ml, hipStream_t st)
 {
-    return cholesky_inverse(h, h->S, h->L, h->Li, h->ldm, (long long)h->ldm * h->ldm, h->B, ml, st);
+    return cholesky_inverse(h, rg.S, rg.L, rg.Li, h->ldm, (long long)h->ldm * h->ldm, rg.B, ml, st);
 }
 
 constexpr int SOLVER_MAX_MT = 11, SOLVER_MAX_NT = 8;
@@ -310,7 +362,7 @@ constexpr int SOLVER_MAX_MT = 11, SOLVER_MAX_NT = 8;
 bool use_fused_solver(int nl, int ml) { return nl <= 16 * SOLVER_MAX_NT && ml <= 16 * SOLVER_MAX_MT; }
 
 template <int MT>
-int launch_gain_solver(slamk_handle* h, int nl, double* Lout, hipStream_t st)
+int launch_gain_solver(slamk_handle* h, const Range& rg, int nl, double* Lout, hipStream_t st)
 {
     const size_t lds = ((size_t)MT * (MT + 1) / 2 * 256 + 9 * 256) * sizeof(double);
     static bool attr_done = false;
@@ -320,34 +372,34 @@ int launch_gain_solver(slamk_handle* h, int nl, double* Lout, hipStream_t st)
         attr_done = true;
     }
     const long long sM = (long long)h->ldm * h->ldm, sNM = (long long)h->ldn * h->ldm;
-    hipLaunchKernelGGL(gain_solver_kernel<MT>, dim3(h->B), dim3(512), lds, st, h->fv, h->W, h->K, (double*)nullptr, Lout,
+    hipLaunchKernelGGL(gain_solver_kernel<MT>, dim3(rg.B), dim3(512), lds, st, rg.fv, rg.W, rg.K, (double*)nullptr, Lout,
                        sM, sNM, nl / 16);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
 
-int run_gain_solver(slamk_handle* h, int nl, int ml, hipStream_t st)
+int run_gain_solver(slamk_handle* h, const Range& rg, int nl, int ml, hipStream_t st)
 {
     ProfScope ps(h, PC_SOLVER, st);
-    double* Lout = (h->B <= 64) ? h->L : nullptr;     // the factor is only kept for slamk_debug_get
+    double* Lout = h->debug ? rg.L : nullptr;         // the factor is only kept for slamk_debug_get
     switch (ml / 16) {
-        case 1: return launch_gain_solver<1>(h, nl, Lout, st);
-        case 2: return launch_gain_solver<2>(h, nl, Lout, st);
-        case 3: return launch_gain_solver<3>(h, nl, Lout, st);
-        case 4: return launch_gain_solver<4>(h, nl, Lout, st);
-        case 5: return launch_gain_solver<5>(h, nl, Lout, st);
-        case 6: return launch_gain_solver<6>(h, nl, Lout, st);
-        case 7: return launch_gain_solver<7>(h, nl, Lout, st);
-        case 8: return launch_gain_solver<8>(h, nl, Lout, st);
-        case 9: return launch_gain_solver<9>(h, nl, Lout, st);
-        case 10: return launch_gain_solver<10>(h, nl, Lout, st);
-        case 11: return launch_gain_solver<11>(h, nl, Lout, st);
+        case 1: return launch_gain_solver<1>(h, rg, nl, Lout, st);
+        case 2: return launch_gain_solver<2>(h, rg, nl, Lout, st);
+        case 3: return launch_gain_solver<3>(h, rg, nl, Lout, st);
+        case 4: return launch_gain_solver<4>(h, rg, nl, Lout, st);
+        case 5: return launch_gain_solver<5>(h, rg, nl, Lout, st);
+        case 6: return launch_gain_solver<6>(h, rg, nl, Lout, st);
+        case 7: return launch_gain_solver<7>(h, rg, nl, Lout, st);
+        case 8: return launch_gain_solver<8>(h, rg, nl, Lout, st);
+        case 9: return launch_gain_solver<9>(h, rg, nl, Lout, st);
+        case 10: return launch_gain_solver<10>(h, rg, nl, Lout, st);
+        case 11: return launch_gain_solver<11>(h, rg, nl, Lout, st);
         default: return fail(h, SLAMK_EINVAL, "gain solver: m = %d out of range", ml);
     }
 }
 
 template <int NT>
-int launch_joseph(slamk_handle* h, int ml, hipStream_t st)
+int launch_joseph(slamk_handle* h, const Range& rg, int ml, hipStream_t st)
 {
     const size_t lds = (size_t)(NT * NT + (NT <= 7 ? 2 : 1) * NT + 2) * 256 * sizeof(double);
     static bool attr_done = false;
@@ -356,119 +408,157 @@ int launch_joseph(slamk_handle* h, int ml, hipStream_t st)
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(joseph_kernel<NT>, dim3(h->B), dim3(512), lds, st, h->fv, h->K, h->ldm,
-                       (long long)h->ldn * h->ldm, ml, h->prm.update_form, h->dx);
+    hipLaunchKernelGGL(joseph_kernel<NT>, dim3(rg.B), dim3(512), lds, st, rg.fv, rg.K, h->ldm,
+                       (long long)h->ldn * h->ldm, ml, h->prm.update_form, rg.dx);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
 
-int run_joseph(slamk_handle* h, int nl, int ml, hipStream_t st)
+int run_joseph(slamk_handle* h, const Range& rg, int nl, int ml, hipStream_t st)
 {
     ProfScope ps(h, PC_GEMM_COV, st);
     switch (nl / 16) {
-        case 1: return launch_joseph<1>(h, ml, st);
-        case 2: return launch_joseph<2>(h, ml, st);
-        case 3: return launch_joseph<3>(h, ml, st);
-        case 4: return launch_joseph<4>(h, ml, st);
-        case 5: return launch_joseph<5>(h, ml, st);
-        case 6: return launch_joseph<6>(h, ml, st);
-        case 7: return launch_joseph<7>(h, ml, st);
-        case 8: return launch_joseph<8>(h, ml, st);
+        case 1: return launch_joseph<1>(h, rg, ml, st);
+        case 2: return launch_joseph<2>(h, rg, ml, st);
+        case 3: return launch_joseph<3>(h, rg, ml, st);
+        case 4: return launch_joseph<4>(h, rg, ml, st);
+        case 5: return launch_joseph<5>(h, rg, ml, st);
+        case 6: return launch_joseph<6>(h, rg, ml, st);
+        case 7: return launch_joseph<7>(h, rg, ml, st);
+        case 8: return launch_joseph<8>(h, rg, ml, st);
         default: return fail(h, SLAMK_EINVAL, "fused covariance update: n = %d out of range", nl);
     }
 }
 
-int run_update(slamk_handle* h, const double* qbw, const double* alt, const double* src, const double* refl,
+int run_update(slamk_handle* h, const Range& rg, const double* qbw, const double* alt, const double* src, const double* refl,
                int* applied, hipStream_t st)
 {
-    const int B = h->B, ldn = h->ldn, ldm = h->ldm;
+    const int B = rg.B, ldn = h->ldn, ldm = h->ldm;
     const int nl = max_nl(h), ml = max_ml(h);
     const long long sN = (long long)ldn * ldn, sNM = (long long)ldn * ldm, sM = (long long)ldm * ldm;
     h->last_nl = nl; h->last_ml = ml;
     int nfmax = 0;
     for (const auto& f : h->hf) nfmax = std::max(nfmax, f.nf);
-    if (!src) src = h->fv.msrc;
-    if (!refl) refl = h->fv.mrefl;
+    if (!src) src = rg.fv.msrc;
+    if (!refl) refl = rg.fv.mrefl;
 
     {
         ProfScope ps(h, PC_FEATURE, st);
-        hipLaunchKernelGGL(measure_kernel, dim3(std::max(1, (nfmax + 63) / 64), B), dim3(64), 0, st, h->fv, qbw, alt,
+        hipLaunchKernelGGL(measure_kernel, dim3(std::max(1, (nfmax + 63) / 64), B), dim3(64), 0, st, rg.fv, qbw, alt,
                            src, refl, ml);
         if (keep_dense(h, nl))
-            hipLaunchKernelGGL(build_H_kernel, dim3((nl + 63) / 64, (ml + 3) / 4, B), dim3(256), 0, st, h->fv, h->Hm,
+            hipLaunchKernelGGL(build_H_kernel, dim3((nl + 63) / 64, (ml + 3) / 4, B), dim3(256), 0, st, rg.fv, rg.Hm,
                                ml, nl);
     }
-    const RowSparse MH{h->fv.ha, h->fv.hb, h->fv.hcs, ldm, 0};
+    const RowSparse MH{rg.fv.ha, rg.fv.hb, rg.fv.hcs, ldm, 0};
     {
     ProfScope ps(h, PC_STRUCT_GAIN, st);
     // W = P H^T                                  (calcK, src/slam/main.cpp:545)
-    launch_right(MH, h->fv.P, ldn, sN, h->W, ldm, sNM, nl, ml, B, st);
+    launch_right(MH, rg.fv.P, ldn, sN, rg.W, ldm, sNM, nl, ml, B, st);
     // S = H W + R, lower part                    (:541-543); the fused solver forms it in LDS itself
     if (!use_fused_solver(nl, ml))
-        launch_left<true>(MH, h->W, ldm, sNM, h->S, ldm, sM, h->fv.rdiag, ldm, ml, ml, B, st);
+        launch_left<true>(MH, rg.W, ldm, sNM, rg.S, ldm, sM, rg.fv.rdiag, ldm, ml, ml, B, st);
     }
     if (use_fused_solver(nl, ml)) {
         // small filters: S = L L^T and K = W L^-T L^-1 (plus K R) in one workgroup per filter
-        int rc = run_gain_solver(h, nl, ml, st);
+        int rc = run_gain_solver(h, rg, nl, ml, st);
         if (rc) return rc;
     } else {
         // S = L L^T, Li = inv(L)
-        int rc = run_cholesky_inverse(h, ml, st);
+        int rc = run_cholesky_inverse(h, rg, ml, st);
         if (rc) return rc;
         ProfScope ps(h, PC_GEMM_GAIN, st);
         // K = W S^-1 = (W Li^T) Li                   (:547-550 solved by Cholesky instead of LU)
         HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_B_KLE_N>(
-                      gargs(h->W, ldm, sNM, h->Li, ldm, sM, h->Y, ldm, sNM, nl, ml, ml), B, st)));
+                      gargs(rg.W, ldm, sNM, rg.Li, ldm, sM, rg.Y, ldm, sNM, nl, ml, ml), B, st)));
         // K and, for the Joseph form, K R (R diagonal) from the same accumulators
-        GemmArgs g = gargs(h->Y, ldm, sNM, h->Li, ldm, sM, h->K, ldm, sNM, nl, ml, ml, 1.0, 0.0, h->fv.rdiag, ldm);
-        g.C2 = h->KR;
+        GemmArgs g = gargs(rg.Y, ldm, sNM, rg.Li, ldm, sM, rg.K, ldm, sNM, nl, ml, ml, 1.0, 0.0, rg.fv.rdiag, ldm);
+        g.C2 = rg.KR;
         HIPCHK(h, (launch_gemm<false, EPI_DUAL_COLSCALE, false, TRI_B_KGE_N>(g, B, st)));
     }
     if (use_fused_solver(nl, ml)) {
         // small filters: A = I - K H, A P and the Joseph (or simple) form in one workgroup per filter
-        int rc = run_joseph(h, nl, ml, st);
+        int rc = run_joseph(h, rg, nl, ml, st);
         if (rc) return rc;
     } else {
-        const double* presym = h->AP;
+        const double* presym = rg.AP;
         bool mirror = false;
         {
         ProfScope ps(h, PC_STRUCT_GAIN, st);
         // A = I - K H                                (updateP, :563-565)
         hipLaunchKernelGGL(eye_minus_kh_kernel, dim3((nl + 63) / 64, (nl + 4 * STRUCT_RPW - 1) / (4 * STRUCT_RPW), B),
-                           dim3(256), 0, st, h->fv, h->K, ldm, sNM, h->Am, nl, STRUCT_RPW);
-        hipLaunchKernelGGL(eye_minus_kh_xcols_kernel, dim3((nl + 3) / 4, B), dim3(256), 0, st, h->fv, h->K, ldm, sNM, h->Am,
+                           dim3(256), 0, st, rg.fv, rg.K, ldm, sNM, rg.Am, nl, STRUCT_RPW);
+        hipLaunchKernelGGL(eye_minus_kh_xcols_kernel, dim3((nl + 3) / 4, B), dim3(256), 0, st, rg.fv, rg.K, ldm, sNM, rg.Am,
                            nl, ml);
         }
         {
         ProfScope ps(h, PC_GEMM_COV, st);
         // AP = A P
         HIPCHK(h, (launch_gemm<false, EPI_NONE, false, TRI_NONE>(
-                      gargs(h->Am, ldn, sN, h->fv.P, ldn, sN, h->AP, ldn, sN, nl, nl, nl), B, st)));
+                      gargs(rg.Am, ldn, sN, rg.fv.P, ldn, sN, rg.AP, ldn, sN, nl, nl, nl), B, st)));
         if (h->prm.update_form == 0) {
             // Joseph: P = AP A^T + (K R) K^T, symmetric by construction: only the lower tiles are computed
             HIPCHK(h, (launch_gemm<true, EPI_NONE, true, TRI_NONE>(
-                          gargs(h->AP, ldn, sN, h->Am, ldn, sN, h->T, ldn, sN, nl, nl, nl), B, st)));
+                          gargs(rg.AP, ldn, sN, rg.Am, ldn, sN, rg.T, ldn, sN, nl, nl, nl), B, st)));
             HIPCHK(h, (launch_gemm<true, EPI_NONE, true, TRI_NONE>(
-                          gargs(h->KR, ldm, sNM, h->K, ldm, sNM, h->T, ldn, sN, nl, nl, ml, 1.0, 1.0), B, st)));
-            presym = h->T;
+                          gargs(rg.KR, ldm, sNM, rg.K, ldm, sNM, rg.T, ldn, sN, nl, nl, ml, 1.0, 1.0), B, st)));
+            presym = rg.T;
             mirror = true;
         }
         }
         ProfScope ps(h, PC_FEATURE, st);
         if (mirror)   // P = the symmetric completion of the lower triangle
             hipLaunchKernelGGL(symmetrize_kernel<true>, dim3((nl + 31) / 32, (nl + 31) / 32, B), dim3(256), 0, st, presym,
-                               h->fv.P, ldn, sN, nl);
+                               rg.fv.P, ldn, sN, nl);
         else          // P = (P + P^T)/2                      (:567)
             hipLaunchKernelGGL(symmetrize_kernel<false>, dim3((nl + 31) / 32, (nl + 31) / 32, B), dim3(256), 0, st, presym,
-                               h->fv.P, ldn, sN, nl);
+                               rg.fv.P, ldn, sN, nl);
     }
     ProfScope ps_tail(h, PC_FEATURE, st);
     // dx = K e, gate, mean update                (main.cpp:228-232)
     if (!use_fused_solver(nl, ml))      // the fused covariance update has already formed dx
-        hipLaunchKernelGGL(gain_kx_kernel, dim3((nl + 15) / 16, B), dim3(256), 0, st, h->fv, h->K, ldm, h->dx, ml);
-    hipLaunchKernelGGL(gain_apply_kernel, dim3(B), dim3(256), 0, st, h->fv, h->dx, applied);
+        hipLaunchKernelGGL(gain_kx_kernel, dim3((nl + 15) / 16, B), dim3(256), 0, st, rg.fv, rg.K, ldm, rg.dx, ml);
+    hipLaunchKernelGGL(gain_apply_kernel, dim3(B), dim3(256), 0, st, rg.fv, rg.dx, applied);
     HIPCHK(h, hipGetLastError());
     return 0;
+}
+
+// Launch sequence of one whole iteration (frame begin, predict, update) for all filters, in `groups` ranges.
+// Leaves the propagated covariance in the T buffer: the caller swaps P and T.
+int step_launch(slamk_handle* h, const double* qbw_dev, const double* w_dev, const double* acc_dev, const double* dt_dev,
+                const double* alt_dev, const double* src_dev, const double* refl_dev, int32_t* applied_dev,
+                hipStream_t st, int groups)
+{
+    const int G = std::max(1, std::min(groups, h->B));
+    if ((int)h->gstreams.size() < G && G > 1) {
+        const size_t old = h->gstreams.size();
+        h->gstreams.resize(G); h->gdone.resize(G);
+        for (size_t g = old; g < (size_t)G; ++g) {
+            HIPCHK(h, hipStreamCreateWithFlags(&h->gstreams[g], hipStreamNonBlocking));
+            HIPCHK(h, hipEventCreateWithFlags(&h->gdone[g], hipEventDisableTiming));
+        }
+    }
+    if (G > 1 && !h->fork) HIPCHK(h, hipEventCreateWithFlags(&h->fork, hipEventDisableTiming));
+    const size_t F = h->F;
+    if (G > 1) HIPCHK(h, hipEventRecord(h->fork, st));
+    int rc = 0;
+    for (int g = 0; g < G && !rc; ++g) {
+        const int b0 = (int)((long long)h->B * g / G), b1 = (int)((long long)h->B * (g + 1) / G);
+        hipStream_t gs = G > 1 ? h->gstreams[g] : st;
+        if (G > 1) HIPCHK(h, hipStreamWaitEvent(gs, h->fork, 0));
+        const Range rp = make_range(h, b0, b1 - b0);
+        hipLaunchKernelGGL(frame_begin_kernel, dim3(rp.B), dim3(256), 0, gs, rp.fv, -1);
+        rc = run_predict(h, rp, qbw_dev + 4 * (size_t)b0, w_dev + 3 * (size_t)b0, acc_dev + 3 * (size_t)b0, dt_dev + b0, gs);
+        if (!rc)
+            rc = run_update(h, after_predict(rp), qbw_dev + 4 * (size_t)b0, (alt_dev ? alt_dev : h->alt_d) + b0,
+                            src_dev ? src_dev + 2 * F * b0 : nullptr, refl_dev ? refl_dev + 2 * F * b0 : nullptr,
+                            applied_dev ? applied_dev + b0 : nullptr, gs);
+        if (G > 1) {
+            HIPCHK(h, hipEventRecord(h->gdone[g], gs));
+            HIPCHK(h, hipStreamWaitEvent(st, h->gdone[g], 0));
+        }
+    }
+    return rc;
 }
 
 // useful flops of one GEMM launch as the kernel executes it (tile skipping and k-range trimming
@@ -564,6 +654,10 @@ int slamk_destroy(slamk_handle* h)
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     for (void* p : h->allocs) (void)hipFree(p);
+    for (auto& g : h->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+    for (auto g : h->gstreams) (void)hipStreamDestroy(g);
+    for (auto e : h->gdone) (void)hipEventDestroy(e);
+    if (h->fork) (void)hipEventDestroy(h->fork);
     delete h;
     return SLAMK_OK;
 }
@@ -818,7 +912,9 @@ int slamk_predict_dev(slamk_handle* h, const double* qbw_dev, const double* w_de
 {
     if (!h || !qbw_dev || !w_dev || !acc_dev || !dt_dev) return SLAMK_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
-    return run_predict(h, qbw_dev, w_dev, acc_dev, dt_dev, (hipStream_t)stream);
+    int rc = run_predict(h, make_range(h, 0, h->B), qbw_dev, w_dev, acc_dev, dt_dev, (hipStream_t)stream);
+    std::swap(h->fv.P, h->T);          // T is whichever of the two covariance-sized buffers is not P
+    return rc;
 }
 
 int slamk_update_dev(slamk_handle* h, const double* qbw_dev, const double* alt_dev, const double* src_dev,
@@ -827,7 +923,70 @@ int slamk_update_dev(slamk_handle* h, const double* qbw_dev, const double* alt_d
     if (!h || !qbw_dev) return SLAMK_EINVAL;
     if (!alt_dev && !h->prm.use_alt_override) return fail(h, SLAMK_EINVAL, "update: alt required without alt_override");
     HIPCHK(h, hipSetDevice(h->device));
-    return run_update(h, qbw_dev, alt_dev ? alt_dev : h->alt_d, src_dev, refl_dev, applied_dev, (hipStream_t)stream);
+    return run_update(h, make_range(h, 0, h->B), qbw_dev, alt_dev ? alt_dev : h->alt_d, src_dev, refl_dev, applied_dev,
+                      (hipStream_t)stream);
+}
+
+// One loop iteration with an image for every filter (src/slam/main.cpp:167-233): frame begin, predict, update.
+// The batch is cut into `groups` ranges that run the whole chain on streams of their own, so that the
+// HBM-bound kernels of one range overlap the LDS-resident per-filter kernels of another; everything is
+// ordered after the work already in `stream` and complete, in stream order, when the call returns.
+int slamk_step_dev(slamk_handle* h, const double* qbw_dev, const double* w_dev, const double* acc_dev,
+                   const double* dt_dev, const double* alt_dev, const double* src_dev, const double* refl_dev,
+                   int32_t* applied_dev, void* stream)
+{
+    if (!h || !qbw_dev || !w_dev || !acc_dev || !dt_dev) return SLAMK_EINVAL;
+    if (!alt_dev && !h->prm.use_alt_override) return fail(h, SLAMK_EINVAL, "step: alt required without alt_override");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (h->graph_mode && !h->prof_on && st != nullptr) {
+        // replay (or first capture) the launch sequence as one hipGraph: one submission per iteration
+        slamk_handle::GraphKey key;
+        memset(&key, 0, sizeof key);
+        const void* ptrs[8] = {qbw_dev, w_dev, acc_dev, dt_dev, alt_dev, src_dev, refl_dev, applied_dev};
+        memcpy(key.p, ptrs, sizeof ptrs);
+        key.P = h->fv.P; key.nl = max_nl(h); key.ml = max_ml(h); key.form = h->prm.update_form;
+        for (const auto& f : h->hf) key.nfmax = std::max(key.nfmax, f.nf);
+        slamk_handle::GraphEntry* hit = nullptr;
+        for (auto& g : h->graphs)
+            if (g.key == key) hit = &g;
+        if (!hit) {
+            if (h->graphs.size() >= 16) {       // layouts come and go with the features: keep the cache small
+                for (auto& g : h->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+                h->graphs.clear();
+            }
+            slamk_handle::GraphEntry e;
+            e.key = key;
+            HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            int rc = step_launch(h, qbw_dev, w_dev, acc_dev, dt_dev, alt_dev, src_dev, refl_dev, applied_dev, st, 1);
+            hipError_t ce = hipStreamEndCapture(st, &e.graph);
+            if (rc) return rc;
+            if (ce != hipSuccess) return fail(h, SLAMK_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+            HIPCHK(h, hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
+            h->graphs.push_back(e);
+            hit = &h->graphs.back();
+        }
+        HIPCHK(h, hipGraphLaunch(hit->exec, st));
+        std::swap(h->fv.P, h->T);
+        return SLAMK_OK;
+    }
+    int rc = step_launch(h, qbw_dev, w_dev, acc_dev, dt_dev, alt_dev, src_dev, refl_dev, applied_dev, st, h->groups);
+    std::swap(h->fv.P, h->T);
+    return rc;
+}
+
+int slamk_set_graph_mode(slamk_handle* h, int on)
+{
+    if (!h) return SLAMK_EINVAL;
+    h->graph_mode = on != 0;
+    return SLAMK_OK;
+}
+
+int slamk_set_pipeline_groups(slamk_handle* h, int groups)
+{
+    if (!h || groups < 1 || groups > 64) return SLAMK_EINVAL;
+    h->groups = groups;
+    return SLAMK_OK;
 }
 
 int slamk_sync(slamk_handle* h, void* stream)
@@ -854,7 +1013,8 @@ int slamk_predict(slamk_handle* h, const double* qbw, const double* w, const dou
     HIPCHK(h, hipMemcpy(h->w_d, w, B * 24, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->acc_d, acc, B * 24, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->dt_d, dt, B * 8, hipMemcpyHostToDevice));
-    int rc = run_predict(h, h->qbw_d, h->w_d, h->acc_d, h->dt_d, 0);
+    int rc = run_predict(h, make_range(h, 0, h->B), h->qbw_d, h->w_d, h->acc_d, h->dt_d, 0);
+    std::swap(h->fv.P, h->T);
     if (rc) return rc;
     HIPCHK(h, hipDeviceSynchronize());
     return SLAMK_OK;
@@ -868,7 +1028,7 @@ int slamk_update(slamk_handle* h, const double* qbw, const double* alt, int* app
     const size_t B = h->B;
     HIPCHK(h, hipMemcpy(h->qbw_d, qbw, B * 32, hipMemcpyHostToDevice));
     if (alt) HIPCHK(h, hipMemcpy(h->alt_d, alt, B * 8, hipMemcpyHostToDevice));
-    int rc = run_update(h, h->qbw_d, h->alt_d, nullptr, nullptr, h->applied_d, 0);
+    int rc = run_update(h, make_range(h, 0, h->B), h->qbw_d, h->alt_d, nullptr, nullptr, h->applied_d, 0);
     if (rc) return rc;
     rc = slamk_sync(h, 0);
     if (applied) HIPCHK(h, hipMemcpy(applied, h->applied_d, B * sizeof(int), hipMemcpyDeviceToHost));
@@ -949,9 +1109,17 @@ int slamk_cholesky_inverse_dev(double* S_dev, double* L_dev, double* Li_dev, int
 }
 
 // ---- introspection -----------------------------------------------------------------------------------
+int slamk_set_debug(slamk_handle* h, int on)
+{
+    if (!h) return SLAMK_EINVAL;
+    h->debug = on != 0;
+    return SLAMK_OK;
+}
+
 int slamk_debug_get(slamk_handle* h, int b, double* H, double* L, double* K, double* e)
 {
     CHECK_B(h, b);
+    if ((H || L) && !h->debug) return fail(h, SLAMK_EINVAL, "debug_get: H and L are only kept after slamk_set_debug(h, 1)");
     HIPCHK(h, hipSetDevice(h->device));
     const int n = 9 + 3 * h->hf[b].nf, m = h->hf[b].m();
     const size_t ldn = h->ldn, ldm = h->ldm;
@@ -965,6 +1133,7 @@ int slamk_debug_get(slamk_handle* h, int b, double* H, double* L, double* K, dou
 int slamk_debug_get_F(slamk_handle* h, int b, double* F)
 {
     CHECK_B(h, b);
+    if (!h->debug) return fail(h, SLAMK_EINVAL, "debug_get_F: F is only kept after slamk_set_debug(h, 1)");
     HIPCHK(h, hipSetDevice(h->device));
     const int n = 9 + 3 * h->hf[b].nf;
     const size_t ldn = h->ldn;

@@ -157,6 +157,18 @@ class FilterBatch:
     def update_dev(self, qbw_dev, alt_dev=None, src_dev=None, refl_dev=None, applied_dev=None, stream=0):
         self._chk(self.L.slamk_update_dev(self.h, qbw_dev, alt_dev, src_dev, refl_dev, applied_dev, stream))
 
+    def step_dev(self, qbw_dev, w_dev, acc_dev, dt_dev, alt_dev=None, src_dev=None, refl_dev=None, applied_dev=None,
+                 stream=0):
+        """frame_begin + predict + update of every filter in one call (device pointers)."""
+        self._chk(self.L.slamk_step_dev(self.h, qbw_dev, w_dev, acc_dev, dt_dev, alt_dev, src_dev, refl_dev,
+                                        applied_dev, stream))
+
+    def set_graph_mode(self, on=True):
+        self._chk(self.L.slamk_set_graph_mode(self.h, int(bool(on))))
+
+    def set_pipeline_groups(self, groups):
+        self._chk(self.L.slamk_set_pipeline_groups(self.h, int(groups)))
+
     def sync(self, stream=0):
         self._chk(self.L.slamk_sync(self.h, stream))
 
@@ -175,6 +187,10 @@ class FilterBatch:
         return {k: (ms[i], cnt[i]) for i, k in enumerate(self.PROFILE_STAGES)}
 
     # ---- introspection -----------------------------------------------------------------------
+    def set_debug(self, on=True):
+        """Keep the dense F, H and L of the last predict/update for debug_get / debug_get_F."""
+        self._chk(self.L.slamk_set_debug(self.h, int(bool(on))))
+
     def debug_get(self, b):
         n, m = 9 + 3 * self.num_features(b), self.num_rows(b)
         H, Lm, K, e = np.zeros((m, n)), np.zeros((m, m)), np.zeros((n, m)), np.zeros(m)

@@ -106,6 +106,7 @@ def test_per_function_parity():
     f = orc.Filter()
     f.X = st.init_pos
     fb = ekf.FilterBatch(max_features=14, batch=1)
+    fb.set_debug(True)
     fb.set_state(0, X=st.init_pos)
     u, quat, ang, acc, dt, matches = inp[0]
     f.update_features(matches, quat)
@@ -147,6 +148,7 @@ def test_reference_jacobian_golden_through_the_kernel():
     g = json.load(open(os.path.join(G, "jacobian_h.json")))
     fh = float.fromhex
     fb = ekf.FilterBatch(max_features=1, batch=1)
+    fb.set_debug(True)
     worst = 0.0
     for c in g["cases"][:48]:
         v = {k: np.array([fh(x) for x in c[k]]) for k in c}
@@ -191,6 +193,81 @@ def test_batch_of_independent_filters():
             assert helpers.rel_err(fb.state_vector(b)[:-3], np.concatenate([a["X"], a["V"], a["pib"].ravel()])) < TOL
             if u & orc.IMG:
                 assert applied[b] == a["applied"]
+
+
+@pytest.mark.parametrize("groups", [1, 3])
+def test_step_call_matches_the_three_calls(groups):
+    import torch
+    """slamk_step_dev (whole iteration, batch cut into ranges on streams of their own) == frame_begin + predict + update."""
+    B, nf = 7, 12
+    st = synth.gen_stream(seed=31, nf=nf, steps=9, churn=False, image_every=1)
+    s0 = st.steps[0]
+    first = [(int(s0.ids[i]), s0.src[i, 0], s0.src[i, 1], s0.refl[i, 0], s0.refl[i, 1]) for i in range(nf)]
+    fbs = []
+    for _ in range(2):
+        fb = ekf.FilterBatch(max_features=nf, batch=B)
+        for b in range(B):
+            fb.set_state(b, X=st.init_pos + 0.01 * b)
+        fb.frame(-1, first, s0.quat)
+        fbs.append(fb)
+    fbs[1].set_pipeline_groups(groups)
+    rng = np.random.default_rng(5)
+    dev = torch.device("cuda")
+    for k in range(1, 9):
+        s, prev = st.steps[k], st.steps[k - 1]
+        one = lambda v: torch.tensor(np.tile(np.asarray(v, dtype=np.float64), (B, 1)), device=dev)
+        q, w, a = one(s.quat), one(s.ang), one(s.acc)
+        dt = torch.full((B,), s.t - prev.t, device=dev, dtype=torch.float64)
+        src = torch.tensor(s.src.T[None] + 1e-3 * rng.standard_normal((B, 2, nf)), device=dev)
+        refl = torch.tensor(s.refl.T[None] * (1 + 1e-3 * rng.standard_normal((B, 2, nf))), device=dev)
+        ap = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+        fbs[0].frame_begin_dev(0)
+        fbs[0].predict_dev(q.data_ptr(), w.data_ptr(), a.data_ptr(), dt.data_ptr(), 0)
+        fbs[0].update_dev(q.data_ptr(), None, src.data_ptr(), refl.data_ptr(), ap[0].data_ptr(), 0)
+        fbs[1].step_dev(q.data_ptr(), w.data_ptr(), a.data_ptr(), dt.data_ptr(), None, src.data_ptr(), refl.data_ptr(),
+                        ap[1].data_ptr(), 0)
+        fbs[0].sync(0)
+        fbs[1].sync(0)
+        assert torch.equal(ap[0], ap[1])
+    for b in range(B):
+        assert np.array_equal(fbs[0].get_cov(b), fbs[1].get_cov(b))
+        assert np.array_equal(fbs[0].state_vector(b), fbs[1].state_vector(b))
+    for fb in fbs:
+        fb.close()
+
+
+def test_graph_mode_replays_the_same_iteration():
+    """Graph mode of slamk_step_dev: captured once per buffer parity, replayed, bit-identical to plain launches."""
+    import torch
+    nf = 20
+    st = synth.gen_stream(seed=32, nf=nf, steps=12, churn=False, image_every=1)
+    s0 = st.steps[0]
+    first = [(int(s0.ids[i]), s0.src[i, 0], s0.src[i, 1], s0.refl[i, 0], s0.refl[i, 1]) for i in range(nf)]
+    fbs = []
+    for _ in range(2):
+        fb = ekf.FilterBatch(max_features=nf, batch=1)
+        fb.set_state(0, X=st.init_pos)
+        fb.frame(0, first, s0.quat)
+        fbs.append(fb)
+    fbs[1].set_graph_mode(True)
+    dev = torch.device("cuda")
+    stream = torch.cuda.Stream(device=dev)
+    buf = {k: torch.zeros(n, dtype=torch.float64, device=dev) for k, n in
+           (("q", 4), ("w", 3), ("a", 3), ("dt", 1), ("src", 2 * nf), ("refl", 2 * nf))}
+    for k in range(1, 12):
+        s, prev = st.steps[k], st.steps[k - 1]
+        with torch.cuda.stream(stream):
+            buf["q"].copy_(torch.tensor(s.quat)); buf["w"].copy_(torch.tensor(s.ang)); buf["a"].copy_(torch.tensor(s.acc))
+            buf["dt"].fill_(s.t - prev.t)
+            buf["src"].copy_(torch.tensor(s.src.T.copy().ravel())); buf["refl"].copy_(torch.tensor(s.refl.T.copy().ravel()))
+        for fb in fbs:
+            fb.step_dev(buf["q"].data_ptr(), buf["w"].data_ptr(), buf["a"].data_ptr(), buf["dt"].data_ptr(), None,
+                        buf["src"].data_ptr(), buf["refl"].data_ptr(), None, stream.cuda_stream)
+            fb.sync(stream.cuda_stream)
+        assert np.array_equal(fbs[0].get_cov(0), fbs[1].get_cov(0)), k
+        assert np.array_equal(fbs[0].state_vector(0), fbs[1].state_vector(0)), k
+    for fb in fbs:
+        fb.close()
 
 
 def test_mixed_feature_counts_in_one_batch():
