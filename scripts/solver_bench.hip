@@ -30,12 +30,29 @@ int main()
     const size_t lds = ((size_t)MT * (MT + 1) / 2 * 256 + 9 * 256) * 8;
     hipFuncSetAttribute(reinterpret_cast<const void*>(gain_solver_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int rep = 0; rep < 3; ++rep) {
+#ifdef SOLVER_STAMPS
+    const int reps = 1;      // the stamp arrays hold one launch
+#else
+    const int reps = 3;
+#endif
+    for (int rep = 0; rep < reps; ++rep) {
         hipEventRecord(e0);
         gain_solver_kernel<MT><<<B, 512, lds>>>(fv, W, K, nullptr, nullptr, sM, sNM, NT);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("%s: %.3f ms\n", VARIANT, ms);
     }
+#ifdef SOLVER_STAMPS
+    long long st[8][128]; int ns[8];
+    hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof st);
+    hipMemcpyFromSymbol(ns, HIP_SYMBOL(g_nstamp), sizeof ns);
+    for (int w = 0; w < 8; ++w) {
+        if (w != 0 && w != 1 && w != 4) continue;
+        const int n = ns[w] < 128 ? ns[w] : 128;
+        printf("wave %d (%d stamps):", w, n);
+        for (int i = 1; i < n; ++i) printf(" %lld", st[w][i] - st[w][i - 1]);
+        printf("  total %lld\n", n > 0 ? st[w][n - 1] - st[w][0] : 0);
+    }
+#endif
     return 0;
 }

@@ -29,6 +29,22 @@
 
 namespace slamk {
 
+#ifdef SOLVER_STAMPS
+// timing build only: per-wavefront cycle stamps of one workgroup
+__device__ long long g_stamps[8][128];
+__device__ int g_nstamp[8];
+#define STAMP()                                                                                         \
+    do {                                                                                                \
+        if (blockIdx.x == SOLVER_STAMPS && (threadIdx.x & 63) == 0) {                                   \
+            const int w_ = threadIdx.x >> 6;                                                            \
+            const int n_ = g_nstamp[w_];                                                                \
+            if (n_ < 128) { g_stamps[w_][n_] = __builtin_readcyclecounter(); g_nstamp[w_] = n_ + 1; }   \
+        }                                                                                               \
+    } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+
 __device__ __forceinline__ int tsw(int r, int c) { return r * 16 + (c ^ (r & 14)); }
 __device__ __forceinline__ int tile_index(int i, int j) { return i * (i + 1) / 2 + j; }
 
@@ -292,23 +308,32 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, const d
     // Per tile column j, two barriers:  A  inv(L_jj) is in place and step j - 1 is complete;
     //                                   B  the panel tiles L_ij are final.
     v4d y[MT];
+    STAMP();                                             // 0: start of S build done (before barrier)
     __syncthreads();
+    STAMP();                                             // 1
     if (wave == 0) {
         // ---- wavefront 0: the chain  L_j+1,j -> S_j+1,j+1 -> factor -> inverse  of the next diagonal tile ----
         diag_tile_factor_invert(lds, lds + NTILES * 256, Lb, ldm, lane);
+        STAMP();                                         // 2: diag(0)
         for (int j = 0; j < MT; ++j) {
             __syncthreads();                             // A
+            STAMP();
             if (j + 1 < MT) panel_tile(j + 1, j);
+            STAMP();
             __syncthreads();                             // B
+            STAMP();
             if (j + 1 < MT) {
                 trail(j + 1, j + 1, j);
+                STAMP();
 #ifndef SOLVER_ABLATE_DIAG
                 diag_tile_factor_invert(lds + tile_index(j + 1, j + 1) * 256, lds + NTILES * 256,
                                         Lb ? Lb + (long long)(16 * (j + 1)) * ldm + 16 * (j + 1) : nullptr, ldm, lane);
 #endif
+                STAMP();
             }
         }
         __syncthreads();
+        STAMP();
         if (has_blk) {                                   // an eighth row block: its forward solve runs here
             const double* Wb = W + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li;
 #pragma unroll
@@ -343,44 +368,62 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, const d
                 for (int r = 0; r < 4; ++r) y[j][r] = stg[tsw(li, lk + 4 * r)];
             }
         }
-        const int wk = wave - 1;                         // 0..6
-        // wavefront 4 shares its SIMD with wavefront 0 and takes no part in the bulk of the trailing update
+        // Wavefront 4 shares its SIMD with wavefront 0: it stays out of the factorisation loop, where that SIMD
+        // belongs to the diagonal-tile chain, and runs its forward solve afterwards, when wavefront 0 is idle.
         const int wk6 = wave < 4 ? wave - 1 : wave - 2;  // 0..5 for wavefronts 1 2 3 5 6 7
+        const bool worker = wave != 4;
+        STAMP();                                         // 2: W preload
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
             __syncthreads();                             // A
+            STAMP();
 #ifndef SOLVER_ABLATE_PANEL
-            for (int i = j + 2 + wk; i < MT; i += 7) panel_tile(i, j);
+            if (worker)
+                for (int i = j + 2 + wk6; i < MT; i += 6) panel_tile(i, j);
 #endif
+            STAMP();
             __syncthreads();                             // B
+            STAMP();
+            if (worker) {
 #ifndef SOLVER_ABLATE_PANEL
-            for (int i = j + 2 + wk; i < MT; i += 7) trail(i, j + 1, j);      // column j + 1 first
+                for (int i = j + 2 + wk6; i < MT; i += 6) trail(i, j + 1, j);      // column j + 1 first
 #endif
 #ifndef SOLVER_ABLATE_TRAIL
-            const int w = MT - j - 2;
+                const int w = MT - j - 2;
 #else
-            const int w = 0;
+                const int w = 0;
 #endif
-            if (wave != 4) {
                 for (int t = wk6; t < w * (w + 1) / 2; t += 6) {
                     int ii = 0;
                     while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
                     const int kk = t - ii * (ii + 1) / 2;
                     trail(j + 2 + ii, j + 2 + kk, j);
                 }
-            }
+                STAMP();
 #if !defined(SOLVER_ABLATE_FWD)
-            if (has_blk) {                               // forward-solve step j
-#else
-            if (false) {
+                if (has_blk) {                           // forward-solve step j
+                    v4d acc = y[j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) acc = tile_mma_regB<false, true>(lds + tile_index(j, k) * 256, y[k], acc, li, lk);
+                    y[j] = tile_mma_regB<false, false>(lds + tile_index(j, j) * 256, acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
+                }
 #endif
+                STAMP();
+            }
+        }
+        __syncthreads();
+        STAMP();
+#if !defined(SOLVER_ABLATE_FWD)
+        if (!worker && has_blk) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
                 v4d acc = y[j];
 #pragma unroll
                 for (int k = 0; k < j; ++k) acc = tile_mma_regB<false, true>(lds + tile_index(j, k) * 256, y[k], acc, li, lk);
                 y[j] = tile_mma_regB<false, false>(lds + tile_index(j, j) * 256, acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
             }
         }
-        __syncthreads();
+#endif
     }
     if (Lb) {   // off-diagonal tiles of L (the diagonal ones were written while they were still L)
         for (int t = wave; t < NTILES; t += 8) {
@@ -408,6 +451,7 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, const d
         y[j] = tile_mma_regB<true, false>(lds + tile_index(j, j) * 256, acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
     }
 #endif
+    STAMP();                                             // backward solve done
     // K tiles leave through the staging tile as well: 128-byte runs per row
     double* Kb = K + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li;
     double* KRb = KR ? KR + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li : nullptr;
@@ -422,6 +466,7 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, const d
             if (KRb) KRb[(long long)(4 * r) * ldm + 16 * j] = v * rd[16 * j + li];
         }
     }
+    STAMP();
 }
 
 }  // namespace slamk
