@@ -29,22 +29,6 @@
 
 namespace slamk {
 
-#ifdef SOLVER_STAMPS
-// timing build only: per-wavefront cycle stamps of one workgroup
-__device__ long long g_stamps[8][128];
-__device__ int g_nstamp[8];
-#define STAMP()                                                                                         \
-    do {                                                                                                \
-        if (blockIdx.x == SOLVER_STAMPS && (threadIdx.x & 63) == 0) {                                   \
-            const int w_ = threadIdx.x >> 6;                                                            \
-            const int n_ = g_nstamp[w_];                                                                \
-            if (n_ < 128) { g_stamps[w_][n_] = __builtin_readcyclecounter(); g_nstamp[w_] = n_ + 1; }   \
-        }                                                                                               \
-    } while (0)
-#else
-#define STAMP() do {} while (0)
-#endif
-
 __device__ __forceinline__ int tsw(int r, int c) { return r * 16 + (c ^ (r & 14)); }
 __device__ __forceinline__ int tile_index(int i, int j) { return i * (i + 1) / 2 + j; }
 
@@ -231,6 +215,115 @@ __device__ __forceinline__ void diag_tile_factor_invert(double* t, double* xs, d
     for (int q = 0; q < 4; ++q) t[tsw(r, 4 * cg + q)] = xrow[q];
 }
 
+// Tile Cholesky of the MT x MT lower tiles in LDS (tile (i, j) at tile_index(i, j)) together with the forward
+// solve Y^T = inv(L) B^T for up to eight 16-column blocks of B^T, one per wavefront.
+//   before: the tiles hold S, and a barrier has been passed since they were written;
+//   after : off-diagonal tiles hold L, diagonal tiles hold inv(L_jj), y[j] holds tile j of Y^T of the
+//           wavefront's block (accumulator layout), and a barrier has been passed.
+// init_tile(j) returns tile j of B^T for the wavefront's block.  Wavefront 0 runs the chain
+//   L_j+1,j -> S_j+1,j+1 -> factor -> inverse   one tile column ahead of the others; per tile column two
+// barriers:  A  inv(L_jj) is in place and step j - 1 is complete;  B  the panel tiles L_ij are final.
+template <int MT, class InitTile>
+__device__ __forceinline__ void tile_cholesky_forward(double* lds, v4d (&y)[MT], bool has_blk, double* Lb, int ldl,
+                                                      int wave, int lane, InitTile init_tile)
+{
+    constexpr int NTILES = MT * (MT + 1) / 2;
+    const int li = lane & 15, lk = lane >> 4;
+    auto panel_tile = [&](int i, int j) {                // L_ij = S_ij inv(L_jj)^T
+        double* tij = lds + tile_index(i, j) * 256;
+        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+        acc = tile_mma_ldsBt<false>(tij, lds + tile_index(j, j) * 256, acc, li, lk);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tij[tsw(lk + 4 * r, li)] = acc[r];
+    };
+    auto trail = [&](int i, int k, int j) {              // S_ik -= L_ij L_kj^T
+        double* tik = lds + tile_index(i, k) * 256;
+        v4d acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = tik[tsw(lk + 4 * r, li)];
+        acc = tile_mma_ldsBt<true>(lds + tile_index(i, j) * 256, lds + tile_index(k, j) * 256, acc, li, lk);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tik[tsw(lk + 4 * r, li)] = acc[r];
+    };
+    // Y^T_j = inv(L_jj) (B^T_j - sum_{k<j} L_jk Y^T_k): a finished tile, lane = column, register = row group,
+    // IS the B operand of the next MFMA.
+    auto forward_step = [&](int j, v4d acc) {
+#pragma unroll
+        for (int k = 0; k < MT; ++k)
+            if (k < j) acc = tile_mma_regB<false, true>(lds + tile_index(j, k) * 256, y[k], acc, li, lk);
+        return tile_mma_regB<false, false>(lds + tile_index(j, j) * 256, acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
+    };
+
+    if (wave == 0) {
+        diag_tile_factor_invert(lds, lds + NTILES * 256, Lb, ldl, lane);
+        for (int j = 0; j < MT; ++j) {
+            __syncthreads();                             // A
+            if (j + 1 < MT) panel_tile(j + 1, j);
+            __syncthreads();                             // B
+            if (j + 1 < MT) {
+                trail(j + 1, j + 1, j);
+                diag_tile_factor_invert(lds + tile_index(j + 1, j + 1) * 256, lds + NTILES * 256,
+                                        Lb ? Lb + (long long)(16 * (j + 1)) * ldl + 16 * (j + 1) : nullptr, ldl, lane);
+            }
+        }
+        __syncthreads();
+        if (has_blk) {                                   // an eighth block: its forward solve runs here
+#pragma unroll
+            for (int j = 0; j < MT; ++j) y[j] = forward_step(j, init_tile(j));
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) y[j] = init_tile(j);
+        // Wavefront 4 shares its SIMD with wavefront 0: it stays out of the factorisation loop, where that SIMD
+        // belongs to the diagonal-tile chain, and runs its forward solve afterwards, when wavefront 0 is idle.
+        const int wk6 = wave < 4 ? wave - 1 : wave - 2;  // 0..5 for wavefronts 1 2 3 5 6 7
+        const bool worker = wave != 4;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            __syncthreads();                             // A
+            if (worker)
+                for (int i = j + 2 + wk6; i < MT; i += 6) panel_tile(i, j);
+            __syncthreads();                             // B
+            if (worker) {
+                for (int i = j + 2 + wk6; i < MT; i += 6) trail(i, j + 1, j);      // column j + 1 first
+                const int w = MT - j - 2;
+                for (int t = wk6; t < w * (w + 1) / 2; t += 6) {
+                    int ii = 0;
+                    while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+                    const int kk = t - ii * (ii + 1) / 2;
+                    trail(j + 2 + ii, j + 2 + kk, j);
+                }
+                if (has_blk) y[j] = forward_step(j, y[j]);
+            }
+        }
+        __syncthreads();
+        if (!worker && has_blk) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j) y[j] = forward_step(j, y[j]);
+        }
+    }
+}
+
+// Off-diagonal tiles of L from LDS to global memory (the diagonal ones are written by the wavefront that
+// factors them, while they are still L).
+template <int MT>
+__device__ __forceinline__ void store_offdiag_tiles(const double* lds, double* Lb, int ldl, int wave, int lane)
+{
+    const int li = lane & 15, lk = lane >> 4;
+    for (int t = wave; t < MT * (MT + 1) / 2; t += 8) {
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= t) ++i;
+        const int j = t - i * (i + 1) / 2;
+        if (i == j) continue;
+        const double* tl = lds + t * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = lk + 4 * r;
+            Lb[(long long)(16 * i + row) * ldl + 16 * j + li] = tl[tsw(row, li)];
+        }
+    }
+}
+
 template <int MT>
 __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, const double* __restrict__ W,
                                                            double* __restrict__ K, double* __restrict__ KR,
@@ -287,162 +380,27 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, const d
             }
         }
     }
-
-    auto panel_tile = [&](int i, int j) {                // L_ij = S_ij inv(L_jj)^T
-        double* tij = lds + tile_index(i, j) * 256;
-        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-        acc = tile_mma_ldsBt<false>(tij, lds + tile_index(j, j) * 256, acc, li, lk);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tij[tsw(lk + 4 * r, li)] = acc[r];
-    };
-    auto trail = [&](int i, int k, int j) {              // S_ik -= L_ij L_kj^T
-        double* tik = lds + tile_index(i, k) * 256;
-        v4d acc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = tik[tsw(lk + 4 * r, li)];
-        acc = tile_mma_ldsBt<true>(lds + tile_index(i, j) * 256, lds + tile_index(k, j) * 256, acc, li, lk);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tik[tsw(lk + 4 * r, li)] = acc[r];
-    };
-
-    // Per tile column j, two barriers:  A  inv(L_jj) is in place and step j - 1 is complete;
-    //                                   B  the panel tiles L_ij are final.
-    v4d y[MT];
-    STAMP();                                             // 0: start of S build done (before barrier)
     __syncthreads();
-    STAMP();                                             // 1
-    if (wave == 0) {
-        // ---- wavefront 0: the chain  L_j+1,j -> S_j+1,j+1 -> factor -> inverse  of the next diagonal tile ----
-        diag_tile_factor_invert(lds, lds + NTILES * 256, Lb, ldm, lane);
-        STAMP();                                         // 2: diag(0)
-        for (int j = 0; j < MT; ++j) {
-            __syncthreads();                             // A
-            STAMP();
-            if (j + 1 < MT) panel_tile(j + 1, j);
-            STAMP();
-            __syncthreads();                             // B
-            STAMP();
-            if (j + 1 < MT) {
-                trail(j + 1, j + 1, j);
-                STAMP();
-#ifndef SOLVER_ABLATE_DIAG
-                diag_tile_factor_invert(lds + tile_index(j + 1, j + 1) * 256, lds + NTILES * 256,
-                                        Lb ? Lb + (long long)(16 * (j + 1)) * ldm + 16 * (j + 1) : nullptr, ldm, lane);
-#endif
-                STAMP();
-            }
-        }
-        __syncthreads();
-        STAMP();
-        if (has_blk) {                                   // an eighth row block: its forward solve runs here
-            const double* Wb = W + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li;
+
+    // ---- factorisation and Y^T = inv(L) W^T ------------------------------------------------------------------
+    // tile (blk, j) of W: rows read as 128-byte runs, transposed through the wavefront's staging tile
+    const double* Wb = Wf + (long long)(16 * (has_blk ? blk : 0) + lk) * ldm + li;
+    v4d y[MT];
+    tile_cholesky_forward<MT>(lds, y, has_blk, Lb, ldm, wave, lane, [&](int j) {
+        double g[4];
 #pragma unroll
-            for (int j = 0; j < MT; ++j) {
-                v4d acc;
+        for (int r = 0; r < 4; ++r) g[r] = Wb[(long long)(4 * r) * ldm + 16 * j];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) stg[tsw(lk + 4 * r, li)] = Wb[(long long)(4 * r) * ldm + 16 * j];
+        for (int r = 0; r < 4; ++r) stg[tsw(lk + 4 * r, li)] = g[r];
+        v4d t;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = stg[tsw(li, lk + 4 * r)];
-#pragma unroll
-                for (int k = 0; k < j; ++k) acc = tile_mma_regB<false, true>(lds + tile_index(j, k) * 256, y[k], acc, li, lk);
-                y[j] = tile_mma_regB<false, false>(lds + tile_index(j, j) * 256, acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
-            }
-        }
-    } else {
-        // ---- wavefronts 1..7: panel, trailing update and Y^T = inv(L) W^T beside the factorisation -----------
-        //   Y^T_j = inv(L_jj) (W^T_j - sum_{k<j} L_jk Y^T_k): a finished tile, lane = column, register = row
-        //   group, IS the B operand of the next MFMA.
-        {
-            // tile (blk, j) of W: rows read as 128-byte runs, transposed through the wavefront's staging tile
-            const double* Wb = W + (long long)b * sNM + (long long)(16 * (has_blk ? blk : 0) + lk) * ldm + li;
-            double g[MT][4];
-#pragma unroll
-            for (int j = 0; j < MT; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) g[j][r] = Wb[(long long)(4 * r) * ldm + 16 * j];
-#pragma unroll
-            for (int j = 0; j < MT; ++j) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) stg[tsw(lk + 4 * r, li)] = g[j][r];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) y[j][r] = stg[tsw(li, lk + 4 * r)];
-            }
-        }
-        // Wavefront 4 shares its SIMD with wavefront 0: it stays out of the factorisation loop, where that SIMD
-        // belongs to the diagonal-tile chain, and runs its forward solve afterwards, when wavefront 0 is idle.
-        const int wk6 = wave < 4 ? wave - 1 : wave - 2;  // 0..5 for wavefronts 1 2 3 5 6 7
-        const bool worker = wave != 4;
-        STAMP();                                         // 2: W preload
-#pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            __syncthreads();                             // A
-            STAMP();
-#ifndef SOLVER_ABLATE_PANEL
-            if (worker)
-                for (int i = j + 2 + wk6; i < MT; i += 6) panel_tile(i, j);
-#endif
-            STAMP();
-            __syncthreads();                             // B
-            STAMP();
-            if (worker) {
-#ifndef SOLVER_ABLATE_PANEL
-                for (int i = j + 2 + wk6; i < MT; i += 6) trail(i, j + 1, j);      // column j + 1 first
-#endif
-#ifndef SOLVER_ABLATE_TRAIL
-                const int w = MT - j - 2;
-#else
-                const int w = 0;
-#endif
-                for (int t = wk6; t < w * (w + 1) / 2; t += 6) {
-                    int ii = 0;
-                    while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
-                    const int kk = t - ii * (ii + 1) / 2;
-                    trail(j + 2 + ii, j + 2 + kk, j);
-                }
-                STAMP();
-#if !defined(SOLVER_ABLATE_FWD)
-                if (has_blk) {                           // forward-solve step j
-                    v4d acc = y[j];
-#pragma unroll
-                    for (int k = 0; k < j; ++k) acc = tile_mma_regB<false, true>(lds + tile_index(j, k) * 256, y[k], acc, li, lk);
-                    y[j] = tile_mma_regB<false, false>(lds + tile_index(j, j) * 256, acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
-                }
-#endif
-                STAMP();
-            }
-        }
-        __syncthreads();
-        STAMP();
-#if !defined(SOLVER_ABLATE_FWD)
-        if (!worker && has_blk) {
-#pragma unroll
-            for (int j = 0; j < MT; ++j) {
-                v4d acc = y[j];
-#pragma unroll
-                for (int k = 0; k < j; ++k) acc = tile_mma_regB<false, true>(lds + tile_index(j, k) * 256, y[k], acc, li, lk);
-                y[j] = tile_mma_regB<false, false>(lds + tile_index(j, j) * 256, acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
-            }
-        }
-#endif
-    }
-    if (Lb) {   // off-diagonal tiles of L (the diagonal ones were written while they were still L)
-        for (int t = wave; t < NTILES; t += 8) {
-            int i = 0;
-            while ((i + 1) * (i + 2) / 2 <= t) ++i;
-            const int j = t - i * (i + 1) / 2;
-            if (i == j) continue;
-            const double* tl = lds + t * 256;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = lk + 4 * r;
-                Lb[(long long)(16 * i + row) * ldm + 16 * j + li] = tl[tsw(row, li)];
-            }
-        }
-    }
+        for (int r = 0; r < 4; ++r) t[r] = stg[tsw(li, lk + 4 * r)];
+        return t;
+    });
+    if (Lb) store_offdiag_tiles<MT>(lds, Lb, ldm, wave, lane);
 
     // ---- K^T_j = inv(L_jj)^T (Y^T_j - sum_{k>j} L_kj^T K^T_k),  j = MT-1 .. 0 -----------------------------
     if (!has_blk) return;
-#ifndef SOLVER_ABLATE_BWD
 #pragma unroll
     for (int j = MT - 1; j >= 0; --j) {
         v4d acc = y[j];
@@ -450,8 +408,6 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, const d
         for (int k = j + 1; k < MT; ++k) acc = tile_mma_regB<true, true>(lds + tile_index(k, j) * 256, y[k], acc, li, lk);
         y[j] = tile_mma_regB<true, false>(lds + tile_index(j, j) * 256, acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
     }
-#endif
-    STAMP();                                             // backward solve done
     // K tiles leave through the staging tile as well: 128-byte runs per row
     double* Kb = K + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li;
     double* KRb = KR ? KR + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li : nullptr;
@@ -466,7 +422,52 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, const d
             if (KRb) KRb[(long long)(4 * r) * ldm + 16 * j] = v * rd[16 * j + li];
         }
     }
-    STAMP();
+}
+
+// Diagonal block of the blocked Cholesky of a large S: factor the 16 MT x 16 MT block at (j0, j0) (lower part
+// valid) into L and write inv(L) of the block into Li, one workgroup per matrix of the batch.  The inverse is
+// the forward solve above with the identity as right-hand side.
+template <int MT>
+__global__ void __launch_bounds__(512) chol_inv_block_kernel(const double* __restrict__ S, double* __restrict__ L,
+                                                              double* __restrict__ Li, int ld, long long sM, int j0)
+{
+    extern __shared__ double lds[];                     // MT (MT + 1) / 2 tiles + one scratch tile
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const long long o = (long long)b * sM + (long long)j0 * ld + j0;
+    const double* Sb = S + o;
+    double* Lb = L + o;
+    double* Lib = Li + o;
+    const int blk = (wave + 7) & 7;
+    const bool has_blk = blk < MT;
+    for (int t = wave; t < MT * (MT + 1) / 2; t += 8) {
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= t) ++i;
+        const int j = t - i * (i + 1) / 2;
+        double* tl = lds + t * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = lk + 4 * r;
+            // the diagonal tiles are completed from their lower triangle
+            const int rr = (i == j && li > row) ? li : row, cc = (i == j && li > row) ? row : li;
+            tl[tsw(row, li)] = Sb[(long long)(16 * i + rr) * ld + 16 * j + cc];
+        }
+    }
+    __syncthreads();
+    v4d y[MT];
+    tile_cholesky_forward<MT>(lds, y, has_blk, Lb, ld, wave, lane, [&](int j) {
+        v4d t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = (j == blk && lk + 4 * r == li) ? 1.0 : 0.0;
+        return t;
+    });
+    store_offdiag_tiles<MT>(lds, Lb, ld, wave, lane);
+    if (!has_blk) return;
+#pragma unroll
+    for (int j = 0; j < MT; ++j)         // tile (j, blk) of inv(L); zero above the diagonal
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Lib[(long long)(16 * j + lk + 4 * r) * ld + 16 * blk + li] = y[j][r];
 }
 
 }  // namespace slamk

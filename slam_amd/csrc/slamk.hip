@@ -296,6 +296,38 @@ Range after_predict(const Range& rg)
     return r;
 }
 
+template <int MT>
+int launch_chol_inv_block_t(slamk_handle* h, double* Sp, double* Lp, double* Lip, int ldm, long long sM, int B, int j0,
+                            hipStream_t st)
+{
+    const size_t lds = ((size_t)MT * (MT + 1) / 2 + 1) * 256 * sizeof(double);
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(chol_inv_block_kernel<MT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(chol_inv_block_kernel<MT>, dim3(B), dim3(512), lds, st, Sp, Lp, Lip, ldm, sM, j0);
+    return 0;
+}
+
+// diagonal block (nb x nb at (j0, j0), nb a multiple of 16 up to 128) of S -> L and inv(L)
+int launch_chol_inv_block(slamk_handle* h, double* Sp, double* Lp, double* Lip, int ldm, long long sM, int B, int j0,
+                          int nb, hipStream_t st)
+{
+    switch (nb / 16) {
+        case 1: return launch_chol_inv_block_t<1>(h, Sp, Lp, Lip, ldm, sM, B, j0, st);
+        case 2: return launch_chol_inv_block_t<2>(h, Sp, Lp, Lip, ldm, sM, B, j0, st);
+        case 3: return launch_chol_inv_block_t<3>(h, Sp, Lp, Lip, ldm, sM, B, j0, st);
+        case 4: return launch_chol_inv_block_t<4>(h, Sp, Lp, Lip, ldm, sM, B, j0, st);
+        case 5: return launch_chol_inv_block_t<5>(h, Sp, Lp, Lip, ldm, sM, B, j0, st);
+        case 6: return launch_chol_inv_block_t<6>(h, Sp, Lp, Lip, ldm, sM, B, j0, st);
+        case 7: return launch_chol_inv_block_t<7>(h, Sp, Lp, Lip, ldm, sM, B, j0, st);
+        case 8: return launch_chol_inv_block_t<8>(h, Sp, Lp, Lip, ldm, sM, B, j0, st);
+        default: return fail(h, SLAMK_EINVAL, "Cholesky diagonal block of %d rows", nb);
+    }
+}
+
 // S (lower) -> L (Cholesky factor) and Li = inv(L); S is used as scratch afterwards.
 int cholesky_inverse(slamk_handle* h, double* Sp, double* Lp, double* Lip, int ldm, long long sM, int B, int ml,
                      hipStream_t st)
@@ -306,12 +338,8 @@ int cholesky_inverse(slamk_handle* h, double* Sp, double* Lp, double* Lip, int l
         const int nb = std::min(NB, ml - j0);
         {
             ProfScope ps(h, PC_POTF2, st);
-            if (NB == 64)
-                hipLaunchKernelGGL(potf2_inv_kernel<64>, dim3(B), dim3(256), (64 * 65 + 4 * 16 * 17) * sizeof(double), st,
-                                   Sp, Lp, Lip, ldm, sM, j0, nb);
-            else
-                hipLaunchKernelGGL(potf2_inv_kernel<128>, dim3(B), dim3(256), (128 * 129 + 8 * 16 * 17) * sizeof(double), st,
-                                   Sp, Lp, Lip, ldm, sM, j0, nb);
+            int rc = launch_chol_inv_block(h, Sp, Lp, Lip, ldm, sM, B, j0, nb, st);
+            if (rc) return rc;
         }
         const int rem = ml - j0 - nb;
         if (rem <= 0) break;
@@ -637,8 +665,6 @@ int slamk_create(const slamk_params* p, int max_features, int batch, int device,
     v.Q0 = h->prm.Q0; v.R0 = h->prm.R0; v.qbias = h->prm.qbias; v.gate = h->prm.gate;
     v.inv_dmax = 1 / h->prm.d_max; v.inv_dmin = 1 / h->prm.d_min;
     v.alt_override = h->prm.alt_override; v.use_alt_override = h->prm.use_alt_override;
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_kernel<128>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (128 * 129 + 8 * 16 * 17) * sizeof(double)));
     hipLaunchKernelGGL(init_cov_kernel, dim3(batch), dim3(64), 0, 0, v.P, h->ldn, (long long)ldn * ldn, h->prm.pinit);
     for (int b = 0; b < batch; ++b) {
         int one = 1;
@@ -1099,12 +1125,6 @@ int slamk_cholesky_inverse_dev(double* S_dev, double* L_dev, double* Li_dev, int
 {
     if (!S_dev || !L_dev || !Li_dev || m < 16 || (m & 15) || ld < m) return SLAMK_EINVAL;
     static thread_local slamk_handle scratch_handle;   // error text / profiling sink for the handle-free call
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_kernel<128>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (128 * 129 + 8 * 16 * 17) * sizeof(double));
-        attr_set = true;
-    }
     return cholesky_inverse(&scratch_handle, S_dev, L_dev, Li_dev, ld, (long long)ld * m, 1, m, (hipStream_t)stream);
 }
 
