@@ -87,6 +87,37 @@ def cpu_baseline(st, steps, nf, k0, k1, budget_s=12.0, max_filters=256):
             "sample": "%d filters x %d steps (nf=%d) of the same batch, oracle/ekf_oracle.c orc_step, 1 thread" % (cnt, k1 - k0, nf)}
 
 
+def ceilings(torch, dev):
+    """Measured ceilings of this box: fp64 MFMA issue rate, the library's own DGEMM, and a device-to-device copy."""
+    import ctypes as C
+    from slam_amd import ekf, _lib
+    out = {"fp64_mfma_issue_tflops": ekf.mfma_f64_probe(4096)}
+    n = 4096
+    A = torch.randn(n, n, dtype=torch.float64, device=dev)
+    Bm = torch.randn(n, n, dtype=torch.float64, device=dev)
+    Cm = torch.zeros(n, n, dtype=torch.float64, device=dev)
+    L = _lib.lib()
+    def gemm():
+        L.slamk_dgemm_dev(1, n, n, n, 1.0, A.data_ptr(), n, 0, Bm.data_ptr(), n, 0, 0.0, Cm.data_ptr(), n, 0, 1, None)
+    gemm()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        gemm()
+    torch.cuda.synchronize(dev)
+    out["dgemm_4096_tflops"] = 5 * 2.0 * n ** 3 / (time.perf_counter() - t0) / 1e12
+    src = torch.empty(1 << 27, dtype=torch.float64, device=dev)      # 1 GiB
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        dst.copy_(src)
+    torch.cuda.synchronize(dev)
+    out["stream_copy_gbs"] = 5 * 2.0 * src.numel() * 8 / (time.perf_counter() - t0) / 1e9
+    return out
+
+
 def single_filter_latency(torch, dev, nf=20, iters=40):
     """configs[1]: one filter, 20 features, latency of one predict+update on one GPU (host-driven)."""
     from slam_amd import ekf
@@ -229,10 +260,28 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t = float(tt.item())
 
+    # multi-rank runs end with the gather of the filter means (outside the timed region)
+    if dist is not None:
+        mine = torch.tensor(np.stack([fb.get_state(b)[0] for b in range(0, B, max(1, B // 8))]), device=dev)
+        allx = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=dev)
+        dist.all_gather_into_tensor(allx, mine)
+        assert bool(torch.isfinite(allx).all())
+
     # sanity on the product of the timed region (never timed): finite, symmetric, positive diagonal
     P = fb.get_cov(B // 2)
     sane = bool(np.all(np.isfinite(P)) and np.array_equal(P, P.T) and np.all(np.diag(P) > 0)
                 and int(applied.sum().item()) == B)
+
+    # predict-only iterations (no image), reported separately
+    torch.cuda.synchronize(dev)
+    tp0 = time.perf_counter()
+    for k in range(W, W + K):
+        s_ = steps[k]
+        fb.predict_dev(s_["qbw"].data_ptr(), s_["w"].data_ptr(), s_["acc"].data_ptr(), s_["dt"].data_ptr(),
+                       stream.cuda_stream)
+    stream.synchronize()
+    t_predict = (time.perf_counter() - tp0) / K
+
 
     if rank == 0:
         # Dominant kernel: gain_solver_kernel (S = H W + R, tile Cholesky, K = W S^-1), one launch per step, timed
@@ -269,6 +318,7 @@ def main():
              "frac": w_bytes / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_bytes("rowsparse_right_kernel")},
         ]
         mfma_ms = solver_ms + cov_ms
+        dense_flops = 8.0 * n ** 3 + 6.0 * n * n * m + 4.0 * n * m * m + m ** 3 / 3.0 + 2.0 * n * m
         out = {
             "metric": "EKF updates/sec (state dim, batch) + fp64 MFMA % of peak, 1/2/4/8 GPUs",
             "value": world * B * K / t, "unit": "EKF updates/s",
@@ -290,6 +340,12 @@ def main():
                                                             / FP64_MATRIX_PEAK_TFLOPS,
                          "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, FETCH_SIZE doubled)"},
             "other_kernels": kernels,
+            # the dense formulation's work (8n^3 + 6n^2 m + 4nm^2 + m^3/3 + 2nm per update) priced at the measured rate:
+            # what an all-GEMM pipeline would have to sustain to match `value`; the sparse Jacobian products skip
+            # most of it, so this is an equivalence, not executed FLOP
+            "dense_model": {"flops_per_update": dense_flops, "equivalent_tflops": world * B * K / t * dense_flops / 1e12 / world,
+                            "equivalent_frac_of_fp64_matrix_peak": B * K / t * dense_flops / 1e12 / FP64_MATRIX_PEAK_TFLOPS},
+            "predict_only": {"ms_per_step": t_predict * 1e3, "predicts_per_s": world * B / t_predict},
             "stages_ms_per_step": {k: round(v[0] / K, 4) for k, v in prof.items()},
             "outputs_sane": sane,
         }
@@ -299,7 +355,8 @@ def main():
         del steps
         torch.cuda.empty_cache()
         if world == 1 and not args.no_extra:
-            out["also"] = {"single_filter": single_filter_latency(torch, dev), "large_map": large_map(torch, dev)}
+            out["also"] = {"single_filter": single_filter_latency(torch, dev), "large_map": large_map(torch, dev),
+                           "ceilings": ceilings(torch, dev)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -76,7 +76,8 @@ __global__ void __launch_bounds__(256) mfma_probe_kernel(double* out, int iters)
     double a = 1.0 + threadIdx.x * 1e-9, bq = 1.0 - threadIdx.x * 1e-9;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc[i], 0, 0, 0);
+        for (int i = 0; i < 8; ++i)      // in-place accumulators: the builtin form is given extra register moves here
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(bq));
     }
     double s = 0;
     for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
