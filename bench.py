@@ -213,8 +213,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # SLAM_BENCH_BACKEND=gloo rehearses the multi-rank path with every rank on the GPUs that exist
+        backend = os.environ.get("SLAM_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+            local = local % torch.cuda.device_count()
     dev = torch.device("cuda", local)
+    cdev = dev if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")   # where collectives run
     torch.cuda.set_device(dev)
 
     from slam_amd import ekf
@@ -256,14 +263,14 @@ def main():
     fb.profile_enable(False)
     fb.sync(stream.cuda_stream)          # also raises on a per-filter status word
     if dist is not None:
-        tt = torch.tensor([t], device=dev, dtype=torch.float64)
+        tt = torch.tensor([t], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t = float(tt.item())
 
     # multi-rank runs end with the gather of the filter means (outside the timed region)
     if dist is not None:
-        mine = torch.tensor(np.stack([fb.get_state(b)[0] for b in range(0, B, max(1, B // 8))]), device=dev)
-        allx = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=dev)
+        mine = torch.tensor(np.stack([fb.get_state(b)[0] for b in range(0, B, max(1, B // 8))]), device=cdev)
+        allx = torch.empty((world * mine.shape[0], mine.shape[1]), dtype=mine.dtype, device=cdev)
         dist.all_gather_into_tensor(allx, mine)
         assert bool(torch.isfinite(allx).all())
 
@@ -292,7 +299,7 @@ def main():
         achieved = solver_flops / (solver_ms * 1e-3) / 1e12
         pmc = {}
         side = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(side):
+        if os.path.exists(side) and B == 4096 and nf == 32:      # the counters were collected on this workload
             try:
                 pmc = json.load(open(side))["kernels"]
             except Exception:
