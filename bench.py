@@ -157,6 +157,31 @@ def single_filter_latency(torch, dev, nf=20, iters=40):
             "latency_us_per_update": t * 1e6, "latency_us_iteration_only": t_iter * 1e6}
 
 
+def sweep_point(torch, dev, nf, B, iters=6):
+    """Updates/s at another (state dim, batch) point: same step as the headline workload, groups = 1."""
+    from slam_amd import ekf
+    st, steps = build_inputs(torch, dev, B, nf, iters + 2, 0)
+    fb = ekf.FilterBatch(max_features=nf, batch=B, device=dev.index or 0)
+    for b in range(B):
+        fb.set_state(b, X=st.init_pos)
+    fb.frame(-1, first_frame(st), st.steps[0].quat)
+    s0 = torch.cuda.Stream(device=dev)
+    def run(k):
+        s = steps[k]
+        fb.step_dev(s["qbw"].data_ptr(), s["w"].data_ptr(), s["acc"].data_ptr(), s["dt"].data_ptr(), None,
+                    s["src"].data_ptr(), s["refl"].data_ptr(), None, s0.cuda_stream)
+    run(0); run(1)
+    fb.sync(s0.cuda_stream)
+    t0 = time.perf_counter()
+    for k in range(2, 2 + iters):
+        run(k)
+    fb.sync(s0.cuda_stream)
+    t = (time.perf_counter() - t0) / iters
+    n, m = 9 + 3 * nf, fb.num_rows(0)
+    fb.close()
+    return {"features": nf, "state_dim": n, "meas_dim": m, "batch": B, "updates_per_s": B / t, "ms_per_step": t * 1e3}
+
+
 def large_map(torch, dev, nf=2000, iters=2):
     """configs[3] on one GPU: one filter with 2000 features (n = 6009, m = 10001)."""
     from slam_amd import ekf
@@ -363,7 +388,9 @@ def main():
         torch.cuda.empty_cache()
         if world == 1 and not args.no_extra:
             out["also"] = {"single_filter": single_filter_latency(torch, dev), "large_map": large_map(torch, dev),
-                           "ceilings": ceilings(torch, dev)}
+                           "ceilings": ceilings(torch, dev),
+                           "sweep": [sweep_point(torch, dev, nf_, B_) for nf_, B_ in
+                                     ((8, 4096), (20, 4096), (32, 512), (32, 16384), (60, 1024))]}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
