@@ -54,7 +54,9 @@ struct slamk_handle {
     double *qbw_d = nullptr, *w_d = nullptr, *acc_d = nullptr, *dt_d = nullptr, *alt_d = nullptr;
     int *applied_d = nullptr;
     int *map_d = nullptr;                 // [ldn] index map for surgery
-    double *feat_tmp = nullptr;           // [4][F] scratch for slot gathers
+    double *feat_tmp = nullptr;           // [B][4][F] scratch for slot gathers
+    int *slots_d = nullptr;               // [F] slots of new features
+    double *sxy_d = nullptr;              // [F][2] their first observations
     std::vector<void*> allocs;
     std::string err;
     hipStream_t stream = nullptr;
@@ -168,30 +170,35 @@ GemmArgs gargs(const double* A, int lda, long long sA, const double* Bp, int ldb
     return g;
 }
 
-// Uploads nf/m/isref/rowoff of filter b from the host mirror.
-int push_layout(slamk_handle* h, int b)
+// Uploads nf/m/isref/rowoff of filters [b0, b0 + cnt), which all share the host mirror of filter b0.
+int push_layout(slamk_handle* h, int b0, int cnt)
 {
-    const HostFilter& f = h->hf[b];
+    const HostFilter& f = h->hf[b0];
     const int F = h->F;
-    std::vector<int> isr(F, 0), ro(F, 0);
+    std::vector<int> isr((size_t)cnt * F, 0), ro((size_t)cnt * F, 0);
     int row = 1;
     for (int i = 0; i < f.nf; ++i) {
         isr[i] = f.isref[i];
         ro[i] = row;
         row += f.isref[i] ? 6 : 4;
     }
-    int nf = f.nf, m = row;
-    HIPCHK(h, hipMemcpy(h->fv.nf + b, &nf, sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(h->fv.m + b, &m, sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(h->fv.isref + (size_t)b * F, isr.data(), F * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(h->fv.rowoff + (size_t)b * F, ro.data(), F * sizeof(int), hipMemcpyHostToDevice));
+    for (int c = 1; c < cnt; ++c) {
+        std::copy(isr.begin(), isr.begin() + F, isr.begin() + (size_t)c * F);
+        std::copy(ro.begin(), ro.begin() + F, ro.begin() + (size_t)c * F);
+    }
+    std::vector<int> nfv(cnt, f.nf), mv(cnt, row);
+    HIPCHK(h, hipMemcpy(h->fv.nf + b0, nfv.data(), cnt * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->fv.m + b0, mv.data(), cnt * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->fv.isref + (size_t)b0 * F, isr.data(), isr.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->fv.rowoff + (size_t)b0 * F, ro.data(), ro.size() * sizeof(int), hipMemcpyHostToDevice));
     return 0;
 }
 
-__global__ void init_features_kernel(FilterView fv, int b, int count, const int* __restrict__ slots,
+__global__ void init_features_kernel(FilterView fv, int count, const int* __restrict__ slots,
                                      const double* __restrict__ sxy, double q1, double q2, double q3, double q4,
                                      double inv_dinit)
 {
+    const int b = blockIdx.y;                  // filter of the (range) view
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     const int i = slots[t], F = fv.F;
@@ -660,7 +667,8 @@ int slamk_create(const slamk_params* p, int max_features, int batch, int device,
     rc |= dalloc(h, &h->dx, B * ldn);
     rc |= dalloc(h, &h->qbw_d, B * 4); rc |= dalloc(h, &h->w_d, B * 3); rc |= dalloc(h, &h->acc_d, B * 3);
     rc |= dalloc(h, &h->dt_d, B); rc |= dalloc(h, &h->alt_d, B); rc |= dalloc(h, &h->applied_d, B);
-    rc |= dalloc(h, &h->map_d, ldn); rc |= dalloc(h, &h->feat_tmp, 4 * F);
+    rc |= dalloc(h, &h->map_d, ldn); rc |= dalloc(h, &h->feat_tmp, B * 4 * F);
+    rc |= dalloc(h, &h->slots_d, F); rc |= dalloc(h, &h->sxy_d, 2 * F);
     if (rc) return SLAMK_EHIP;
     v.Q0 = h->prm.Q0; v.R0 = h->prm.R0; v.qbias = h->prm.qbias; v.gate = h->prm.gate;
     v.inv_dmax = 1 / h->prm.d_max; v.inv_dmin = 1 / h->prm.d_min;
@@ -761,7 +769,7 @@ int slamk_set_features(slamk_handle* h, int b, int nf, const int32_t* id, const 
     if (up(h->fv.pib, pib, 3, t3) || up(h->fv.anchor, anchor, 3, t3) || up(h->fv.q0, q0, 4, t4) ||
         up(h->fv.pib0, pib0, 2, t2))
         return SLAMK_EHIP;
-    return push_layout(h, b);
+    return push_layout(h, b, 1);
 }
 
 int slamk_get_features(slamk_handle* h, int b, int* nf_out, int32_t* id, double* pib, double* anchor, double* q0,
@@ -788,14 +796,18 @@ int slamk_get_features(slamk_handle* h, int b, int* nf_out, int32_t* id, double*
 }
 
 // ---- image frame ------------------------------------------------------------------------------
-static int frame_one(slamk_handle* h, int b, const slamk_match* matches, int nmatch, const double quat[4])
-{
-    const int F = h->F, ldn = h->ldn;
-    HostFilter& f = h->hf[b];
-    // old_pos = X, depth clamp (main.cpp:168, states.cpp:91-103)
-    hipLaunchKernelGGL(frame_begin_kernel, dim3(1), dim3(256), 0, 0, h->fv, b);
+// What a frame does to the feature list of one host mirror (States::update_features, states.cpp:104-200).
+struct FramePlan {
+    int old_nf = 0, nf = 0;
+    std::vector<int32_t> nid;       // ids after the frame, slot order
+    std::vector<uint8_t> nisr;
+    std::vector<int> nsrc;          // previous slot of every new slot, -1 = fresh
+    std::vector<int> nfresh;        // index into the matches for fresh slots, else -1
+    bool identity = true;
+};
 
-    // ---- association on the host mirror (States::update_features, states.cpp:104-200) ----
+static int plan_frame(slamk_handle* h, const HostFilter& f, const slamk_match* matches, int nmatch, FramePlan& p)
+{
     const int old_nf = f.nf;
     std::vector<int32_t> ids = f.id;
     std::vector<uint8_t> isr = f.isref;
@@ -823,75 +835,88 @@ static int frame_one(slamk_handle* h, int b, const slamk_match* matches, int nma
         }
     }
     // erase what is still unmatched, keeping order
-    std::vector<int32_t> nid; std::vector<uint8_t> nisr; std::vector<int> nsrc, nfresh;
+    p = FramePlan();
+    p.old_nf = old_nf;
     for (size_t i = 0; i < ids.size(); ++i) {
         if (nomatch[i] != 0) continue;
-        nid.push_back(ids[i]); nisr.push_back(isr[i]); nsrc.push_back(srcslot[i]); nfresh.push_back(fresh_of[i]);
+        p.nid.push_back(ids[i]); p.nisr.push_back(isr[i]); p.nsrc.push_back(srcslot[i]); p.nfresh.push_back(fresh_of[i]);
     }
-    const int nf = (int)nid.size();
-    if (nf > F) return fail(h, SLAMK_ECAPACITY, "frame: %d features exceed max_features=%d", nf, F);
+    p.nf = (int)p.nid.size();
+    if (p.nf > h->F) return fail(h, SLAMK_ECAPACITY, "frame: %d features exceed max_features=%d", p.nf, h->F);
+    p.identity = (p.nf == old_nf);
+    for (int i = 0; i < p.nf && p.identity; ++i) p.identity = (p.nsrc[i] == i);
+    return SLAMK_OK;
+}
 
-    bool identity = (nf == old_nf);
-    for (int i = 0; i < nf && identity; ++i) identity = (nsrc[i] == i);
-
-    if (!identity) {
+// Applies one plan to the filters [b0, b0 + cnt), whose host mirrors are identical: every device step is
+// one launch over the whole range.
+static int apply_frame(slamk_handle* h, int b0, int cnt, const FramePlan& p, const slamk_match* matches, int nmatch,
+                       const double quat[4])
+{
+    const int F = h->F, ldn = h->ldn, nf = p.nf, old_nf = p.old_nf;
+    const Range rg = make_range(h, b0, cnt);
+    // old_pos = X, depth clamp (main.cpp:168, states.cpp:91-103)
+    hipLaunchKernelGGL(frame_begin_kernel, dim3(cnt), dim3(256), 0, 0, rg.fv, -1);
+    if (!p.identity) {
         // per-feature containers: copy out, gather back
-        struct Arr { double* p; int nc; } arrs[4] = {{h->fv.pib, 3}, {h->fv.anchor, 3}, {h->fv.q0, 4}, {h->fv.pib0, 2}};
+        struct Arr { double* q; int nc; } arrs[4] = {{rg.fv.pib, 3}, {rg.fv.anchor, 3}, {rg.fv.q0, 4}, {rg.fv.pib0, 2}};
         std::vector<int> smap(std::max(1, nf));
-        for (int i = 0; i < nf; ++i) smap[i] = nsrc[i];
+        for (int i = 0; i < nf; ++i) smap[i] = p.nsrc[i];
         HIPCHK(h, hipMemcpy(h->map_d, smap.data(), smap.size() * sizeof(int), hipMemcpyHostToDevice));
         for (auto& a : arrs) {
-            double* live = a.p + (size_t)b * a.nc * F;
-            HIPCHK(h, hipMemcpyAsync(h->feat_tmp, live, (size_t)a.nc * F * sizeof(double), hipMemcpyDeviceToDevice, 0));
-            if (nf) hipLaunchKernelGGL(gather_slots_kernel, dim3((nf + 255) / 256), dim3(256), 0, 0, h->feat_tmp, live,
+            HIPCHK(h, hipMemcpyAsync(h->feat_tmp, a.q, (size_t)cnt * a.nc * F * sizeof(double), hipMemcpyDeviceToDevice, 0));
+            if (nf) hipLaunchKernelGGL(gather_slots_kernel, dim3((nf + 255) / 256, cnt), dim3(256), 0, 0, h->feat_tmp, a.q,
                                        h->map_d, F, nf, a.nc);
         }
-        HIPCHK(h, hipDeviceSynchronize());
         // covariance rows/cols: one gather through the state-index map
         const int n_new = 9 + 3 * nf, nl = pad16(std::max(n_new, 9 + 3 * old_nf));
         std::vector<int> imap(ldn, -2);
         for (int c = 0; c < 6; ++c) imap[c] = c;
         for (int i = 0; i < nf; ++i)
-            for (int c = 0; c < 3; ++c) imap[6 + 3 * i + c] = nsrc[i] >= 0 ? 6 + 3 * nsrc[i] + c : -1;
+            for (int c = 0; c < 3; ++c) imap[6 + 3 * i + c] = p.nsrc[i] >= 0 ? 6 + 3 * p.nsrc[i] + c : -1;
         for (int c = 0; c < 3; ++c) imap[6 + 3 * nf + c] = 6 + 3 * old_nf + c;
         HIPCHK(h, hipMemcpy(h->map_d, imap.data(), ldn * sizeof(int), hipMemcpyHostToDevice));
-        double* Pb = h->fv.P + (size_t)b * ldn * ldn;
-        double* Tb = h->T + (size_t)b * ldn * ldn;
-        hipLaunchKernelGGL(remap_cov_kernel, dim3((nl + 63) / 64, (nl + 3) / 4), dim3(256), 0, 0, Pb, Tb, h->map_d, ldn,
-                           nl, h->prm.p0);
-        HIPCHK(h, hipMemcpyAsync(Pb, Tb, (size_t)nl * ldn * sizeof(double), hipMemcpyDeviceToDevice, 0));
-        HIPCHK(h, hipDeviceSynchronize());
+        const long long sN = (long long)ldn * ldn;
+        hipLaunchKernelGGL(remap_cov_kernel, dim3((nl + 63) / 64, (nl + 3) / 4, cnt), dim3(256), 0, 0, rg.fv.P, rg.T,
+                           h->map_d, ldn, sN, nl, h->prm.p0);
+        hipLaunchKernelGGL(copy_block_kernel, dim3((nl + 63) / 64, (nl + 3) / 4, cnt), dim3(256), 0, 0, rg.T, rg.fv.P, ldn,
+                           sN, nl, nl);
     }
-    f.nf = nf; f.id = nid; f.isref = nisr;
-    int rc = push_layout(h, b);
+    for (int c = 0; c < cnt; ++c) {
+        HostFilter& f = h->hf[b0 + c];
+        f.nf = nf; f.id = p.nid; f.isref = p.nisr;
+    }
+    int rc = push_layout(h, b0, cnt);
     if (rc) return rc;
     // new features: Feature(X, sense, match)  feature.cpp:41-91
     std::vector<int> slots; std::vector<double> sxy;
     for (int i = 0; i < nf; ++i)
-        if (nfresh[i] >= 0) { slots.push_back(i); sxy.push_back(matches[nfresh[i]].sx); sxy.push_back(matches[nfresh[i]].sy); }
+        if (p.nfresh[i] >= 0) {
+            slots.push_back(i); sxy.push_back(matches[p.nfresh[i]].sx); sxy.push_back(matches[p.nfresh[i]].sy);
+        }
     if (!slots.empty()) {
-        int* slots_d = nullptr; double* sxy_d = nullptr;
-        HIPCHK(h, hipMalloc(&slots_d, slots.size() * sizeof(int)));
-        HIPCHK(h, hipMalloc(&sxy_d, sxy.size() * sizeof(double)));
-        HIPCHK(h, hipMemcpy(slots_d, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(h, hipMemcpy(sxy_d, sxy.data(), sxy.size() * sizeof(double), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(init_features_kernel, dim3(((int)slots.size() + 63) / 64), dim3(64), 0, 0, h->fv, b,
-                           (int)slots.size(), slots_d, sxy_d, quat[0], quat[1], quat[2], quat[3], 1 / h->prm.dinit);
-        HIPCHK(h, hipDeviceSynchronize());
-        (void)hipFree(slots_d); (void)hipFree(sxy_d);
+        HIPCHK(h, hipMemcpy(h->slots_d, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->sxy_d, sxy.data(), sxy.size() * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(init_features_kernel, dim3(((int)slots.size() + 63) / 64, cnt), dim3(64), 0, 0, rg.fv,
+                           (int)slots.size(), h->slots_d, h->sxy_d, quat[0], quat[1], quat[2], quat[3], 1 / h->prm.dinit);
     }
     // keep the frame's observations in slot order (the id search of measurementModel, main.cpp:362-375)
-    std::vector<double> ms(2 * F, 0.0), mr(2 * F, 0.0);
+    std::vector<double> ms((size_t)cnt * 2 * F, 0.0), mr((size_t)cnt * 2 * F, 0.0);
     for (int i = 0; i < nf; ++i) {
         const slamk_match* mt = nullptr;
         for (int k = 0; k < nmatch; ++k)
-            if (matches[k].id == nid[i]) { mt = &matches[k]; break; }
+            if (matches[k].id == p.nid[i]) { mt = &matches[k]; break; }
         if (!mt) return fail(h, SLAMK_ENOMATCH, "Cannot find match.");
         ms[i] = mt->sx; ms[F + i] = mt->sy;
         mr[i] = mt->rx; mr[F + i] = mt->ry;
     }
-    HIPCHK(h, hipMemcpy(h->fv.msrc + (size_t)b * 2 * F, ms.data(), 2 * F * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(h->fv.mrefl + (size_t)b * 2 * F, mr.data(), 2 * F * sizeof(double), hipMemcpyHostToDevice));
+    for (int c = 1; c < cnt; ++c) {
+        std::copy(ms.begin(), ms.begin() + 2 * F, ms.begin() + (size_t)c * 2 * F);
+        std::copy(mr.begin(), mr.begin() + 2 * F, mr.begin() + (size_t)c * 2 * F);
+    }
+    HIPCHK(h, hipMemcpy(rg.fv.msrc, ms.data(), ms.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(rg.fv.mrefl, mr.data(), mr.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipDeviceSynchronize());
     return SLAMK_OK;
 }
 
@@ -899,10 +924,20 @@ int slamk_frame(slamk_handle* h, int b, const slamk_match* matches, int nmatch, 
 {
     if (!h || nmatch < 0 || (nmatch && !matches) || !quat) return SLAMK_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
-    if (b >= 0) { CHECK_B(h, b); return frame_one(h, b, matches, nmatch, quat); }
-    for (int i = 0; i < h->B; ++i) {
-        int rc = frame_one(h, i, matches, nmatch, quat);
+    FramePlan plan;
+    if (b >= 0) {
+        CHECK_B(h, b);
+        int rc = plan_frame(h, h->hf[b], matches, nmatch, plan);
+        return rc ? rc : apply_frame(h, b, 1, plan, matches, nmatch, quat);
+    }
+    // the same frame for every filter: runs of filters with identical feature lists share one plan
+    for (int i = 0; i < h->B;) {
+        int j = i + 1;
+        while (j < h->B && h->hf[j].nf == h->hf[i].nf && h->hf[j].id == h->hf[i].id && h->hf[j].isref == h->hf[i].isref) ++j;
+        int rc = plan_frame(h, h->hf[i], matches, nmatch, plan);
+        if (!rc) rc = apply_frame(h, i, j - i, plan, matches, nmatch, quat);
         if (rc) return rc;
+        i = j;
     }
     return SLAMK_OK;
 }

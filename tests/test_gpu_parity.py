@@ -195,6 +195,44 @@ def test_batch_of_independent_filters():
                 assert applied[b] == a["applied"]
 
 
+def test_shared_frame_with_feature_churn_is_applied_to_the_whole_batch():
+    """frame(-1, ...) (one association, batched surgery) == frame(b, ...) per filter, with features replaced,
+    dropped and added along the stream; filter 0 also follows the oracle."""
+    B, nf = 5, 10
+    st = synth.gen_stream(seed=41, nf=nf, steps=40, churn=True, drop_at=12, drop_count=3, add_at=24, add_count=4)
+    so, _ = helpers.run_oracle(st)
+    inp = helpers.stream_inputs(st, 7)
+    fbs = [ekf.FilterBatch(max_features=nf + 5, batch=B) for _ in range(2)]
+    for fb in fbs:
+        for b in range(B):
+            fb.set_state(b, X=st.init_pos + np.array([0.0, 0.003 * b, 0.0]))
+    for b in range(B):
+        fbs[0].frame(b, inp[0][5], inp[0][1])
+    fbs[1].frame(-1, inp[0][5], inp[0][1])
+    counts = set()
+    for k in range(1, len(inp)):
+        u, quat, ang, acc, dt, matches = inp[k]
+        if u & orc.IMG:
+            for b in range(B):
+                fbs[0].frame(b, matches, quat)
+            fbs[1].frame(-1, matches, quat)
+        for fb in fbs:
+            fb.predict(np.tile(quat, B), np.tile(ang, B), np.tile(acc, B), np.full(B, dt))
+            if u & orc.IMG:
+                fb.update(np.tile(quat, B))
+        counts.add(fbs[1].num_features(0))
+        a = so[k - 1]
+        assert helpers.rel_err(fbs[1].get_cov(0), a["P"]) < TOL
+        assert list(fbs[1].get_features(0)["ids"]) == list(a["ids"])
+    assert len(counts) > 1
+    for b in range(B):
+        assert np.array_equal(fbs[0].get_cov(b), fbs[1].get_cov(b))
+        assert np.array_equal(fbs[0].state_vector(b), fbs[1].state_vector(b))
+        assert list(fbs[0].get_features(b)["ids"]) == list(fbs[1].get_features(b)["ids"])
+    for fb in fbs:
+        fb.close()
+
+
 @pytest.mark.parametrize("groups", [1, 3])
 def test_step_call_matches_the_three_calls(groups):
     import torch
