@@ -155,6 +155,21 @@ int slamk_stage_motion_dev(slamk_handle* h, const double* qbw_dev, const double*
 /* measurementModel / jacobianH / initR (main.cpp:348-408,449-476,575-624): innovation, diag R, dense H. */
 int slamk_stage_measure_dev(slamk_handle* h, const double* qbw_dev, const double* alt_dev, const double* src_dev,
                             const double* refl_dev, void* stream);
+/* Row-block products with the Jacobians in compact form (filter 0 of the handle; slamk_stage_motion_dev /
+ * slamk_stage_measure_dev must have run).  which: 0 = F, 1 = H.
+ *   right: Out[rows x mrows] = In[rows x n] * M^T                      (T_r = P_r F^T, W_r = P_r H^T)
+ *   left : Out[rows x cols]  = M[row0 .. row0+rows, :] * In[n x cols]  (+ diag Q / R on the operator's diagonal)
+ *   eye_minus_kh: A[rows x n] = I[row0 .., :] - K[rows x m] H          (src/slam/main.cpp:563-565)
+ *   gain : Y = W Li^T, K = Y Li, KR = K diag(r) for a row block of W   (src/slam/main.cpp:545-550)
+ * Rows past the operator (padding of a row-block layout) are not written. */
+int slamk_stage_right_dev(slamk_handle* h, int which, const double* In_dev, int ldi, int rows, double* Out_dev, int ldo,
+                          void* stream);
+int slamk_stage_left_dev(slamk_handle* h, int which, int row0, int rows, const double* In_dev, int ldi, int cols,
+                         double* Out_dev, int ldo, int add_diag, void* stream);
+int slamk_stage_eye_minus_kh_dev(slamk_handle* h, const double* K_dev, int ldk, int row0, int rows, double* A_dev,
+                                 int lda, void* stream);
+int slamk_stage_gain_dev(slamk_handle* h, const double* W_dev, int rows, int m, int ld, const double* Li_dev, int ldli,
+                         double* Y_dev, double* K_dev, double* KR_dev, const double* r_dev, void* stream);
 /* dx = K e with the caller's gain K (n x m, leading dimension ldk), gate and mean update (main.cpp:228-232). */
 int slamk_stage_apply_dev(slamk_handle* h, const double* K_dev, int ldk, int32_t* applied_dev, void* stream);
 /* Device address and shape of one of the handle's matrices (filter 0): which = 0 F, 1 H, 2 innovation e,

@@ -239,7 +239,7 @@ void launch_left(const RowSparse& M, const double* In, int ldi, long long sIn, d
 {
     hipLaunchKernelGGL(rowsparse_left_kernel<LOWER>,
                        dim3((cols + 63) / 64, (rows + 4 * STRUCT_RPW - 1) / (4 * STRUCT_RPW), B), dim3(256), 0, st, M, In,
-                       ldi, sIn, Out, ldo, sOut, diag, sDiag, rows, cols, STRUCT_RPW);
+                       ldi, sIn, Out, ldo, sOut, diag, sDiag, rows, cols, STRUCT_RPW, 0);
 }
 
 // A contiguous range of the filters of a handle: the device view and the workspaces, offset to its first filter.
@@ -522,9 +522,9 @@ int run_update(slamk_handle* h, const Range& rg, const double* qbw, const double
         ProfScope ps(h, PC_STRUCT_GAIN, st);
         // A = I - K H                                (updateP, :563-565)
         hipLaunchKernelGGL(eye_minus_kh_kernel, dim3((nl + 63) / 64, (nl + 4 * STRUCT_RPW - 1) / (4 * STRUCT_RPW), B),
-                           dim3(256), 0, st, rg.fv, rg.K, ldm, sNM, rg.Am, nl, STRUCT_RPW);
+                           dim3(256), 0, st, rg.fv, rg.K, ldm, sNM, rg.Am, ldn, sN, nl, nl, 0, STRUCT_RPW);
         hipLaunchKernelGGL(eye_minus_kh_xcols_kernel, dim3((nl + 3) / 4, B), dim3(256), 0, st, rg.fv, rg.K, ldm, sNM, rg.Am,
-                           nl, ml);
+                           ldn, sN, nl, 0, ml);
         }
         {
         ProfScope ps(h, PC_GEMM_COV, st);
@@ -1104,8 +1104,10 @@ int slamk_stage_motion_dev(slamk_handle* h, const double* qbw_dev, const double*
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     const int nl = max_nl(h);
-    hipLaunchKernelGGL(build_F_kernel, dim3((nl + 63) / 64, (nl + 3) / 4, h->B), dim3(256), 0, st, h->fv, qbw_dev,
-                       w_dev, dt_dev, h->Fm, nl);
+    hipLaunchKernelGGL(motion_rows_kernel, dim3((nl + 255) / 256, h->B), dim3(256), 0, st, h->fv, qbw_dev, w_dev, dt_dev, nl);
+    if (h->debug)
+        hipLaunchKernelGGL(build_F_kernel, dim3((nl + 63) / 64, (nl + 3) / 4, h->B), dim3(256), 0, st, h->fv, qbw_dev,
+                           w_dev, dt_dev, h->Fm, nl);
     hipLaunchKernelGGL(dynamics_kernel, dim3(h->B), dim3(256), 0, st, h->fv, qbw_dev, w_dev, acc_dev, dt_dev);
     HIPCHK(h, hipGetLastError());
     return SLAMK_OK;
@@ -1123,8 +1125,89 @@ int slamk_stage_measure_dev(slamk_handle* h, const double* qbw_dev, const double
     hipLaunchKernelGGL(measure_kernel, dim3(std::max(1, (nfmax + 63) / 64), h->B), dim3(64), 0, st, h->fv, qbw_dev,
                        alt_dev ? alt_dev : h->alt_d, src_dev ? src_dev : h->fv.msrc, refl_dev ? refl_dev : h->fv.mrefl,
                        ml);
-    hipLaunchKernelGGL(build_H_kernel, dim3((nl + 63) / 64, (ml + 3) / 4, h->B), dim3(256), 0, st, h->fv, h->Hm, ml, nl);
+    if (h->debug)
+        hipLaunchKernelGGL(build_H_kernel, dim3((nl + 63) / 64, (ml + 3) / 4, h->B), dim3(256), 0, st, h->fv, h->Hm, ml, nl);
     HIPCHK(h, hipGetLastError());
+    return SLAMK_OK;
+}
+
+// which: 0 = the motion Jacobian F (nl rows), 1 = the measurement Jacobian H (ml rows), filter 0 of the handle
+static bool stage_operator(slamk_handle* h, int which, RowSparse* M, int* mrows, const double** diag)
+{
+    if (which == 0) { *M = RowSparse{h->fv.fa, h->fv.fg, h->fv.fgs, h->ldn, 3}; *mrows = max_nl(h); *diag = h->fv.qdiag; }
+    else if (which == 1) { *M = RowSparse{h->fv.ha, h->fv.hb, h->fv.hcs, h->ldm, 0}; *mrows = max_ml(h); *diag = h->fv.rdiag; }
+    else return false;
+    return true;
+}
+
+int slamk_stage_right_dev(slamk_handle* h, int which, const double* In_dev, int ldi, int rows, double* Out_dev, int ldo,
+                          void* stream)
+{
+    RowSparse M; int mrows; const double* diag;
+    if (!h || !In_dev || !Out_dev || rows < 0 || !stage_operator(h, which, &M, &mrows, &diag)) return SLAMK_EINVAL;
+    if (ldi < max_nl(h) || ldo < mrows) return fail(h, SLAMK_EINVAL, "stage_right: leading dimensions too small");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (rows) launch_right(M, In_dev, ldi, 0, Out_dev, ldo, 0, rows, mrows, 1, (hipStream_t)stream);
+    HIPCHK(h, hipGetLastError());
+    return SLAMK_OK;
+}
+
+int slamk_stage_left_dev(slamk_handle* h, int which, int row0, int rows, const double* In_dev, int ldi, int cols,
+                         double* Out_dev, int ldo, int add_diag, void* stream)
+{
+    RowSparse M; int mrows; const double* diag;
+    if (!h || !In_dev || !Out_dev || row0 < 0 || rows < 0 || cols < 0 || !stage_operator(h, which, &M, &mrows, &diag))
+        return SLAMK_EINVAL;
+    if (ldi < cols || ldo < cols) return fail(h, SLAMK_EINVAL, "stage_left: leading dimensions too small");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int r = std::max(0, std::min(rows, mrows - row0));     // rows past the operator are left to the caller (zero)
+    if (r && cols) {
+        M.ca += 3 * (size_t)row0; M.cb += 3 * (size_t)row0; M.cs += row0;
+        hipStream_t st = (hipStream_t)stream;
+        if (add_diag)
+            hipLaunchKernelGGL(rowsparse_left_kernel<false>,
+                               dim3((cols + 63) / 64, (r + 4 * STRUCT_RPW - 1) / (4 * STRUCT_RPW), 1), dim3(256), 0, st, M,
+                               In_dev, ldi, 0LL, Out_dev, ldo, 0LL, diag + row0, 0LL, r, cols, STRUCT_RPW, row0);
+        else      // a diagonal column no lane reaches
+            hipLaunchKernelGGL(rowsparse_left_kernel<false>,
+                               dim3((cols + 63) / 64, (r + 4 * STRUCT_RPW - 1) / (4 * STRUCT_RPW), 1), dim3(256), 0, st, M,
+                               In_dev, ldi, 0LL, Out_dev, ldo, 0LL, diag + row0, 0LL, r, cols, STRUCT_RPW, -(1 << 30));
+    }
+    HIPCHK(h, hipGetLastError());
+    return SLAMK_OK;
+}
+
+int slamk_stage_eye_minus_kh_dev(slamk_handle* h, const double* K_dev, int ldk, int row0, int rows, double* A_dev, int lda,
+                                 void* stream)
+{
+    if (!h || !K_dev || !A_dev || row0 < 0 || rows < 0) return SLAMK_EINVAL;
+    const int nl = max_nl(h), ml = max_ml(h);
+    if (ldk < ml || lda < nl) return fail(h, SLAMK_EINVAL, "stage_eye_minus_kh: leading dimensions too small");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (rows) {
+        hipLaunchKernelGGL(eye_minus_kh_kernel, dim3((nl + 63) / 64, (rows + 4 * STRUCT_RPW - 1) / (4 * STRUCT_RPW), 1),
+                           dim3(256), 0, st, h->fv, K_dev, ldk, 0LL, A_dev, lda, 0LL, nl, rows, row0, STRUCT_RPW);
+        hipLaunchKernelGGL(eye_minus_kh_xcols_kernel, dim3((rows + 3) / 4, 1), dim3(256), 0, st, h->fv, K_dev, ldk, 0LL,
+                           A_dev, lda, 0LL, rows, row0, ml);
+    }
+    HIPCHK(h, hipGetLastError());
+    return SLAMK_OK;
+}
+
+// Y = W Li^T, K = Y Li and K R = K diag(r) for `rows` rows of W (m x m lower-triangular Li, m a multiple of 16).
+int slamk_stage_gain_dev(slamk_handle* h, const double* W_dev, int rows, int m, int ld, const double* Li_dev, int ldli,
+                         double* Y_dev, double* K_dev, double* KR_dev, const double* r_dev, void* stream)
+{
+    if (!h || !W_dev || !Li_dev || !Y_dev || !K_dev || !KR_dev || !r_dev || rows < 16 || (rows & 15) || m < 16 || (m & 15))
+        return SLAMK_EINVAL;
+    if (ld < m || ldli < m) return fail(h, SLAMK_EINVAL, "stage_gain: leading dimensions too small");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_B_KLE_N>(gargs(W_dev, ld, 0, Li_dev, ldli, 0, Y_dev, ld, 0, rows, m, m), 1, st)));
+    GemmArgs g = gargs(Y_dev, ld, 0, Li_dev, ldli, 0, K_dev, ld, 0, rows, m, m, 1.0, 0.0, r_dev, 0);
+    g.C2 = KR_dev;
+    HIPCHK(h, (launch_gemm<false, EPI_DUAL_COLSCALE, false, TRI_B_KGE_N>(g, 1, st)));
     return SLAMK_OK;
 }
 

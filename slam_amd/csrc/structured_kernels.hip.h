@@ -129,15 +129,16 @@ __global__ void __launch_bounds__(256) rowsparse_right_kernel(RowSparse M, const
     }
 }
 
-// Out[q][l] = sum_k M[q][k] In[k][l] (+ diag[q] on q == l), M row-sparse with `rows` rows; lanes along l.
+// Out[q][l] = sum_k M[q][k] In[k][l] (+ diag[q] on q + dcol == l), M row-sparse with `rows` rows; lanes along l.
 // LOWER: row q is skipped by wavefronts whose 64 columns all lie right of column (q | 127).
 // grid (ceil(cols / 64), ceil(rows / (4 rpw)), B), 256 threads.
 template <bool LOWER>
 __global__ void __launch_bounds__(256) rowsparse_left_kernel(RowSparse M, const double* __restrict__ In, int ldi,
                                                               long long sIn, double* __restrict__ Out, int ldo,
                                                               long long sOut, const double* __restrict__ diag,
-                                                              long long sDiag, int rows, int cols, int rpw)
+                                                              long long sDiag, int rows, int cols, int rpw, int dcol)
 {
+    // dcol: column of row 0's diagonal element (non-zero when M, diag and Out start at a later row of the operator)
     const int b = blockIdx.z;
     const int l0 = blockIdx.x * 64;
     const int l = l0 + (threadIdx.x & 63);
@@ -175,7 +176,7 @@ __global__ void __launch_bounds__(256) rowsparse_left_kernel(RowSparse M, const 
             acc = a0 * x0; acc = fma(a1, x1, acc); acc = fma(a2, x2, acc);
             acc = fma(b0, y0, acc); acc = fma(b1, y1, acc); acc = fma(b2, y2, acc);
         }
-        if (q == l) acc += dg[q];
+        if (q + dcol == l) acc += dg[q];
         Ob[(long long)q * ldo + l] = acc;
     }
 }
@@ -255,30 +256,33 @@ __global__ void __launch_bounds__(256) predict_cov_kernel(FilterView fv, const d
 // A = I - K H (updateP, src/slam/main.cpp:563-565), columns 3 .. nl-1.  Column 6 + 3 i + c only meets the
 // measurement rows of feature i; the velocity, bias and padding columns meet none.  Lanes along the column.
 // grid (ceil(nl / 64), ceil(nl / (4 rpw)), B), 256 threads.
+// K holds `rows` rows of the gain, the first of them row `row0` of the filter (for the unit diagonal); A has
+// leading dimension lda and batch stride sA.
 __global__ void __launch_bounds__(256) eye_minus_kh_kernel(FilterView fv, const double* __restrict__ K, int ldk,
-                                                            long long sK, double* __restrict__ A, int nl, int rpw)
+                                                            long long sK, double* __restrict__ A, int lda, long long sA,
+                                                            int nl, int rows, int row0, int rpw)
 {
     const int b = blockIdx.z;
     const int l = blockIdx.x * 64 + (threadIdx.x & 63);
     const int j0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * rpw;
     if (l >= nl) return;
     const int nf = fv.nf[b];
-    int row0 = 0, cnt = 0, c = 0;
+    int frow = 0, cnt = 0, c = 0;
     if (l >= 6 && l < 6 + 3 * nf) {
         const int i = (l - 6) / 3;
         c = (l - 6) - 3 * i;
-        row0 = fv.rowoff[(long long)b * fv.F + i];
+        frow = fv.rowoff[(long long)b * fv.F + i];
         cnt = fv.isref[(long long)b * fv.F + i] ? 6 : 4;
     }
-    const double* hb = fv.hb + ((long long)b * fv.ldm + row0) * 3 + c;
+    const double* hb = fv.hb + ((long long)b * fv.ldm + frow) * 3 + c;
     double h[6];
 #pragma unroll
     for (int t = 0; t < 6; ++t) h[t] = (t < cnt) ? hb[3 * t] : 0.0;
-    const double* Kb = K + (long long)b * sK + row0;
-    double* Ab = A + (long long)b * fv.ldn * fv.ldn;
+    const double* Kb = K + (long long)b * sK + frow;
+    double* Ab = A + (long long)b * sA;
     for (int r = 0; r < rpw; ++r) {
         const int j = j0 + r;
-        if (j >= nl) break;
+        if (j >= rows) break;
         if (l < 3) continue;                           // written by eye_minus_kh_xcols_kernel
         const double* kr = Kb + (long long)j * ldk;
         double acc = 0.0;
@@ -288,19 +292,20 @@ __global__ void __launch_bounds__(256) eye_minus_kh_kernel(FilterView fv, const 
             for (int t = 1; t < 6; ++t)
                 if (t < cnt) acc = fma(kr[t], h[t], acc);
         }
-        Ab[(long long)j * fv.ldn + l] = (j == l ? 1.0 : 0.0) - acc;
+        Ab[(long long)j * lda + l] = (j + row0 == l ? 1.0 : 0.0) - acc;
     }
 }
 
 // Columns 0..2 of A = I - K H: every measurement row has position entries.  One wavefront per row of K.
 // grid (ceil(nl / 4), B), 256 threads.
 __global__ void __launch_bounds__(256) eye_minus_kh_xcols_kernel(FilterView fv, const double* __restrict__ K, int ldk,
-                                                                  long long sK, double* __restrict__ A, int nl, int ml)
+                                                                  long long sK, double* __restrict__ A, int lda,
+                                                                  long long sA, int rows, int row0, int ml)
 {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= nl) return;
+    if (j >= rows) return;
     const double* kr = K + (long long)b * sK + (long long)j * ldk;
     const double* ha = fv.ha + (long long)b * fv.ldm * 3;
     double s0 = 0, s1 = 0, s2 = 0;
@@ -317,7 +322,7 @@ __global__ void __launch_bounds__(256) eye_minus_kh_xcols_kernel(FilterView fv, 
     }
     if (lane < 3) {
         const double s = lane == 0 ? s0 : (lane == 1 ? s1 : s2);
-        A[(long long)b * fv.ldn * fv.ldn + (long long)j * fv.ldn + lane] = (j == lane ? 1.0 : 0.0) - s;
+        A[(long long)b * sA + (long long)j * lda + lane] = (j + row0 == lane ? 1.0 : 0.0) - s;
     }
 }
 

@@ -28,16 +28,46 @@ class OracleBackend:
 
     def motion(self, qbw, w, acc, dt):
         s = orc.make_sensors(quat=qbw, acc=acc, ang=w)
-        F = self.f.motion_jacobian(s, float(dt))
+        self.Fm = torch.from_numpy(self.f.motion_jacobian(s, float(dt)))
         self.f.dynamics_step(s, float(dt))
-        qd = orc.init_q_diag(self.f.nf, float(dt))
-        return torch.from_numpy(F), torch.from_numpy(qd)
+        self.qd = torch.from_numpy(orc.init_q_diag(self.f.nf, float(dt)))
+        return self.qd
 
     def measure(self, qbw, src=None, refl=None):
         meas, hmu, H, ref = self.f.measurement_model(self.old_pos, self.alt, self.matches, qbw)
         self.e = meas - hmu
-        rd = orc.init_r_diag(ref)
-        return torch.from_numpy(H), torch.from_numpy(self.e), torch.from_numpy(rd)
+        self.Hm = torch.from_numpy(H)
+        self.rd = torch.from_numpy(orc.init_r_diag(ref))
+        return torch.from_numpy(self.e), self.rd
+
+    def _op(self, which):
+        return (self.Fm, self.qd) if which == 0 else (self.Hm, self.rd)
+
+    def right(self, which, Out, In):
+        M, _ = self._op(which)
+        Out[:, :M.shape[0]] = In[:, :M.shape[1]] @ M.T
+
+    def left(self, which, Out, row0, In, add_diag):
+        M, d = self._op(which)
+        rows = max(0, min(Out.shape[0], M.shape[0] - row0))
+        if rows == 0:
+            return
+        Out[:rows] = M[row0:row0 + rows] @ In[:M.shape[1]]
+        if add_diag:
+            idx = torch.arange(rows)
+            Out[idx, row0 + idx] += d[row0:row0 + rows]
+
+    def eye_minus_kh(self, A, K, row0):
+        n, m = self.dims()
+        A[:, :n] = -(K[:, :m] @ self.Hm)
+        for j in range(A.shape[0]):
+            if row0 + j < n:
+                A[j, row0 + j] += 1.0
+
+    def gain(self, Y, K, KR, W, Li, rd):
+        Y.copy_(W @ Li.T)
+        K.copy_(Y @ Li)
+        KR.copy_(K * rd[None, :Li.shape[0]])
 
     def gemm(self, Cm, A, Bm, trans_b, alpha=1.0, beta=0.0):
         prod = A @ (Bm.T if trans_b else Bm)
