@@ -30,12 +30,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("SLAM_BENCH_BACKEND", "nccl")     # gloo: rehearsal with every rank on the GPUs that exist
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     from slam_amd import ekf, synth
     from slam_amd.sharded import HipBackend, ShardedLargeMapFilter
     nf = args.nf

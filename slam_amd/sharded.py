@@ -180,6 +180,12 @@ class ShardedLargeMapFilter:
         if self.world == 1:
             return
         import torch.distributed as dist
+        if full.is_cuda and dist.get_backend(self.group) != "nccl":
+            # rehearsal on a backend without device collectives (gloo): stage through host memory
+            host = torch.empty(full.shape, dtype=full.dtype)
+            dist.all_gather_into_tensor(host, own.cpu().contiguous(), group=self.group)
+            full.copy_(host)
+            return
         dist.all_gather_into_tensor(full, own.contiguous(), group=self.group)
 
     def gather_cov(self):

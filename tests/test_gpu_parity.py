@@ -453,3 +453,54 @@ def test_sharded_filter_hip_backend_single_rank():
     P = sh.gather_cov().cpu().numpy()
     assert helpers.rel_err(P, f.P) < TOL
     assert helpers.rel_err(fb.state_vector(0), f.state_vector()) < TOL
+
+
+def _sharded_hip_worker(rank, world, port, nf, steps, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from slam_amd.sharded import HipBackend, ShardedLargeMapFilter
+        st = synth.gen_stream(seed=17, nf=nf, steps=steps, churn=False)
+        inp = helpers.stream_inputs(st, 7)
+        dev = torch.device("cuda", 0)
+        fb = ekf.FilterBatch(max_features=nf, batch=1)
+        fb.set_state(0, X=st.init_pos)
+        fb.frame(0, inp[0][5], inp[0][1])
+        be = HipBackend(fb, dev)
+        sh = ShardedLargeMapFilter(be, rank, world)
+        sh.load_cov(torch.from_numpy(fb.get_cov(0)).to(dev))
+        t = lambda v: torch.tensor(np.asarray(v, dtype=np.float64), device=dev)
+        for k in range(1, steps):
+            u, quat, ang, acc, dt, matches = inp[k]
+            if u & orc.IMG:
+                fb.frame(0, matches, quat)
+            sh.predict(t(quat), t(ang), t(acc), t([dt]))
+            if u & orc.IMG:
+                sh.update(t(quat))
+        be.sync()
+        P = sh.gather_cov().cpu().numpy()
+        if rank == 0:
+            np.save(out, np.concatenate([P.ravel(), fb.state_vector(0)]))
+        fb.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_filter_hip_backend_two_ranks_on_one_gpu(tmp_path):
+    """Two ranks of the sharded filter, both on GPU 0, all-gathers rehearsed over gloo (staged through the host):
+    the row-block stage calls with row0 > 0 against the oracle."""
+    import socket
+    import torch.multiprocessing as mp
+    nf, steps, world = 45, 7, 2
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    out = str(tmp_path / "res.npy")
+    mp.spawn(_sharded_hip_worker, args=(world, port, nf, steps, out), nprocs=world, join=True)
+    res = np.load(out)
+    st = synth.gen_stream(seed=17, nf=nf, steps=steps, churn=False)
+    so, f = helpers.run_oracle(st)
+    n = 9 + 3 * nf
+    assert helpers.rel_err(res[:n * n].reshape(n, n), f.P) < TOL
+    assert helpers.rel_err(res[n * n:], f.state_vector()) < TOL
