@@ -180,6 +180,16 @@ int slamk_buffer_dev(slamk_handle* h, int which, double** ptr, int* rows, int* c
 int slamk_cholesky_inverse_dev(double* S_dev, double* L_dev, double* Li_dev, int m, int ld, void* stream);
 
 /* ---- introspection for tests and benchmarks (no counterpart in the reference) ----------- */
+/* ----- batched forms of the stream pre-processing filters that feed the estimator (device pointers) ----- */
+/* src/euler2qbw/euler2qbw.cpp:37-46: n rows (phi, theta, psi) -> n scalar-last quaternions. */
+int slamk_pre_euler2qbw_dev(const double* euler_dev, double* q_dev, int n, void* stream);
+/* src/rotate/main.cpp:146-154: out = R(q) v for n vectors; q as given, never normalised (Quaternion.cpp:32-47). */
+int slamk_pre_rotate_dev(const double q[4], const double* v_dev, double* out_dev, int n, void* stream);
+/* src/img2body/img2body.cpp:31-67: n pixels (x, y) -> body-frame ratios (Y1/Y0, Y2/Y0), compiled-in camera. */
+int slamk_pre_img2body_dev(const double* px_dev, double* out_dev, int n, void* stream);
+/* src/lpf/fir.cpp:39-49,105-115: 3-channel FIR, y[i] = sum_k x[i-k] coeffs[k], zero history; x and y distinct. */
+int slamk_pre_fir_dev(const double* coeffs_dev, int order, const double* x_dev, double* y_dev, int n, void* stream);
+
 /* Introspection is opt-in: after slamk_set_debug(h, 1) every predict/update also writes the dense F, H and
  * the Cholesky factor L, which the products themselves never need. */
 int slamk_set_debug(slamk_handle* h, int on);

@@ -109,6 +109,20 @@ void orc_euler2quaternion(double phi, double theta, double psi, double q[4])
     q[3] = cos(phi / 2) * cos(theta / 2) * cos(psi / 2) + sin(phi / 2) * sin(theta / 2) * sin(psi / 2);
 }
 
+/* src/lpf/fir.cpp:39-49 (filter) driven as main() does, :105-115: one channel, ring buffer of `order` zeros */
+void orc_fir(const double *coeffs, int order, const double *x, double *y, int n)
+{
+    double *ring = (double *)calloc((size_t)order, sizeof(double));
+    for (int i = 0; i < n; ++i) {
+        const int index = i % order;
+        ring[index] = x[i];
+        double acc = 0;
+        for (int k = 0; k < order; ++k) acc += ring[(order + index - k) % order] * coeffs[k];
+        y[i] = acc;
+    }
+    free(ring);
+}
+
 /* src/img2body/img2body.cpp:31-37,46-67 */
 void orc_image2body(double px, double py, double *bx, double *by)
 {

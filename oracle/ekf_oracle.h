@@ -94,6 +94,8 @@ void orc_rotation(const double q[4], double R[9]);
 void orc_euler2quaternion(double phi, double theta, double psi, double q[4]);
 /* src/img2body/img2body.cpp:46-67 (uses orc_rotation) */
 void orc_image2body(double px, double py, double *bx, double *by);
+/* src/lpf/fir.cpp:39-49,105-115, one channel */
+void orc_fir(const double *coeffs, int order, const double *x, double *y, int n);
 
 /* src/ARC/feature.cpp:143-198 */
 void orc_xib_hat(const double pib[3], double out[3]);

@@ -68,6 +68,7 @@ def lib():
         L.orc_jacobian_h.argtypes = [dp, dp, C.POINTER(Feature), dp, dp]
         L.orc_image2body.argtypes = [C.c_double, C.c_double, dp, dp]
         L.orc_euler2quaternion.argtypes = [C.c_double, C.c_double, C.c_double, dp]
+        L.orc_fir.argtypes = [dp, C.c_int, dp, dp, C.c_int]
         L.orc_motion_jacobian.argtypes = [C.POINTER(FilterS), C.POINTER(Sensors), C.c_double, dp]
         L.orc_dynamics_step.argtypes = [C.POINTER(FilterS), C.POINTER(Sensors), C.c_double]
         L.orc_measurement_model.restype = C.c_int
@@ -113,6 +114,15 @@ def euler2quaternion(phi, theta, psi):
     q = np.zeros(4)
     lib().orc_euler2quaternion(phi, theta, psi, _dp(q))
     return q
+
+
+def fir(coeffs, x):
+    """src/lpf/fir.cpp on one channel."""
+    c = np.ascontiguousarray(coeffs, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros_like(x)
+    lib().orc_fir(_dp(c), len(c), _dp(x), _dp(y), len(x))
+    return y
 
 
 def image2body(px, py):

@@ -59,6 +59,10 @@ SIGNATURES = {
     "slamk_stage_apply_dev": (C.c_int, [_H, _vp, C.c_int, _vp, _vp]),
     "slamk_buffer_dev": (C.c_int, [_H, C.c_int, C.POINTER(_vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "slamk_cholesky_inverse_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "slamk_pre_euler2qbw_dev": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "slamk_pre_rotate_dev": (C.c_int, [C.POINTER(C.c_double), _vp, _vp, C.c_int, _vp]),
+    "slamk_pre_img2body_dev": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "slamk_pre_fir_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp]),
     "slamk_set_debug": (C.c_int, [C.c_void_p, C.c_int]),
     "slamk_debug_get": (C.c_int, [_H, C.c_int, _vp, _vp, _vp, _vp]),
     "slamk_debug_get_F": (C.c_int, [_H, C.c_int, _vp]),

@@ -18,6 +18,7 @@
 #include "linalg_kernels.hip.h"
 #include "structured_kernels.hip.h"
 #include "joseph_kernel.hip.h"
+#include "preprocess_kernels.hip.h"
 
 using namespace slamk;
 
@@ -1244,6 +1245,37 @@ int slamk_cholesky_inverse_dev(double* S_dev, double* L_dev, double* Li_dev, int
     if (!S_dev || !L_dev || !Li_dev || m < 16 || (m & 15) || ld < m) return SLAMK_EINVAL;
     static thread_local slamk_handle scratch_handle;   // error text / profiling sink for the handle-free call
     return cholesky_inverse(&scratch_handle, S_dev, L_dev, Li_dev, ld, (long long)ld * m, 1, m, (hipStream_t)stream);
+}
+
+// ---- stream pre-processing filters, batched --------------------------------------------------------------
+int slamk_pre_euler2qbw_dev(const double* euler_dev, double* q_dev, int n, void* stream)
+{
+    if (n < 0 || (n && (!euler_dev || !q_dev))) return SLAMK_EINVAL;
+    if (n) hipLaunchKernelGGL(euler2qbw_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, euler_dev, q_dev, n);
+    return hipGetLastError() == hipSuccess ? SLAMK_OK : SLAMK_EHIP;
+}
+
+int slamk_pre_rotate_dev(const double q[4], const double* v_dev, double* out_dev, int n, void* stream)
+{
+    if (!q || n < 0 || (n && (!v_dev || !out_dev))) return SLAMK_EINVAL;
+    if (n) hipLaunchKernelGGL(rotate_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, q[0], q[1], q[2],
+                              q[3], v_dev, out_dev, n);
+    return hipGetLastError() == hipSuccess ? SLAMK_OK : SLAMK_EHIP;
+}
+
+int slamk_pre_img2body_dev(const double* px_dev, double* out_dev, int n, void* stream)
+{
+    if (n < 0 || (n && (!px_dev || !out_dev))) return SLAMK_EINVAL;
+    if (n) hipLaunchKernelGGL(img2body_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, px_dev, out_dev, n);
+    return hipGetLastError() == hipSuccess ? SLAMK_OK : SLAMK_EHIP;
+}
+
+int slamk_pre_fir_dev(const double* coeffs_dev, int order, const double* x_dev, double* y_dev, int n, void* stream)
+{
+    if (order < 1 || n < 0 || !coeffs_dev || (n && (!x_dev || !y_dev)) || x_dev == y_dev) return SLAMK_EINVAL;
+    if (n) hipLaunchKernelGGL(fir_kernel, dim3((3 * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, coeffs_dev, x_dev,
+                              y_dev, order, n);
+    return hipGetLastError() == hipSuccess ? SLAMK_OK : SLAMK_EHIP;
 }
 
 // ---- introspection -----------------------------------------------------------------------------------

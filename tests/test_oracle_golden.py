@@ -84,3 +84,11 @@ def test_jacobian_h_is_the_derivative_of_the_predictions():
             assert np.allclose(num, Hb[:, c], rtol=1e-5, atol=1e-6)
             num = (h(X, pib + d) - h(X, pib - d)) / (2 * eps)
             assert np.allclose(num, Hi[:, c], rtol=1e-5, atol=1e-6)
+
+
+def test_fir_ring_buffer_equals_causal_convolution():
+    """src/lpf/fir.cpp:39-49: the ring-buffer walk is y[i] = sum_k x[i-k] c[k] with zero history."""
+    rng = np.random.default_rng(2)
+    for order, n in ((1, 4), (5, 3), (16, 200)):
+        c, x = rng.standard_normal(order), rng.standard_normal(n)
+        assert np.allclose(orc.fir(c, x), np.convolve(x, c)[:n], rtol=1e-13, atol=1e-13)
