@@ -36,7 +36,9 @@ enum {
     SLAMK_ENOMATCH = -3,    /* "Cannot find match."            src/slam/main.cpp:372-375 */
     SLAMK_EREFL = -4,       /* reflection rows of H, R, e disagree: the reference aborts in
                                cv::Mat arithmetic here (src/slam/main.cpp:211-218,353; src/ARC/view.cpp:17,39) */
-    SLAMK_ECAPACITY = -5    /* more features than max_features */
+    SLAMK_ECAPACITY = -5,   /* more features than max_features */
+    SLAMK_ENOTSPD = -6      /* S = H P H^T + R not positive definite: the Cholesky gain does not exist (the
+                               reference's LU solve, main.cpp:549, goes on silently); reported by slamk_sync */
 };
 
 /* Compile-time constants of the reference, as run-time parameters with the same defaults:
@@ -143,7 +145,7 @@ int slamk_set_pipeline_groups(slamk_handle* h, int groups);
  * of about ten launches: what a single small filter's latency is made of).  `stream` must not be the null
  * stream; stage timing (slamk_profile_enable) turns graph mode off for the calls it covers. */
 int slamk_set_graph_mode(slamk_handle* h, int on);
-/* Waits for `stream` and returns SLAMK_EREFL / SLAMK_OK from the per-filter status words. */
+/* Waits for `stream` and returns SLAMK_EREFL / SLAMK_ENOTSPD / SLAMK_OK from the per-filter status words. */
 int slamk_sync(slamk_handle* h, void* stream);
 
 /* ---- stage-level entry points: the pieces a row-block sharded large-map filter needs around its

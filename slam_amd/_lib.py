@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslamk.so")
 
-SLAMK_OK, SLAMK_EINVAL, SLAMK_EHIP, SLAMK_ENOMATCH, SLAMK_EREFL, SLAMK_ECAPACITY = 0, -1, -2, -3, -4, -5
+SLAMK_OK, SLAMK_EINVAL, SLAMK_EHIP, SLAMK_ENOMATCH, SLAMK_EREFL, SLAMK_ECAPACITY, SLAMK_ENOTSPD = 0, -1, -2, -3, -4, -5, -6
 
 
 class Params(C.Structure):

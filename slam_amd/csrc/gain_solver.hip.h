@@ -71,7 +71,7 @@ __device__ __forceinline__ double rsqrt_nr(double a)
 }
 
 // Lower triangle of a 4 x 4 block packed by rows: (i, j) at i (i + 1) / 2 + j.
-// l = chol(d), id[k] = 1 / l_kk.
+// l = chol(d), id[k] = 1 / l_kk.  A pivot that is not positive turns into NaN or infinity and spreads from there.
 __device__ __forceinline__ void chol4(const double* d, double* l, double* id)
 {
     id[0] = rsqrt_nr(d[0]);
@@ -411,6 +411,7 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, const d
     // K tiles leave through the staging tile as well: 128-byte runs per row
     double* Kb = K + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li;
     double* KRb = KR ? KR + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li : nullptr;
+    double mag = 0.0;                                    // a pivot that was not positive has made K NaN or infinite
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
 #pragma unroll
@@ -418,10 +419,12 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, const d
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const double v = stg[tsw(lk + 4 * r, li)];
+            mag += fabs(v);
             Kb[(long long)(4 * r) * ldm + 16 * j] = v;
             if (KRb) KRb[(long long)(4 * r) * ldm + 16 * j] = v * rd[16 * j + li];
         }
     }
+    if (!(mag < 1.0e300)) atomicOr(fv.status + b, 2);    // S was not positive definite
 }
 
 // Diagonal block of the blocked Cholesky of a large S: factor the 16 MT x 16 MT block at (j0, j0) (lower part
@@ -429,7 +432,8 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, const d
 // the forward solve above with the identity as right-hand side.
 template <int MT>
 __global__ void __launch_bounds__(512) chol_inv_block_kernel(const double* __restrict__ S, double* __restrict__ L,
-                                                              double* __restrict__ Li, int ld, long long sM, int j0)
+                                                              double* __restrict__ Li, int ld, long long sM, int j0,
+                                                              int* __restrict__ status)
 {
     extern __shared__ double lds[];                     // MT (MT + 1) / 2 tiles + one scratch tile
     const int b = blockIdx.x;
@@ -464,10 +468,16 @@ __global__ void __launch_bounds__(512) chol_inv_block_kernel(const double* __res
     });
     store_offdiag_tiles<MT>(lds, Lb, ld, wave, lane);
     if (!has_blk) return;
+    double mag = 0.0;
 #pragma unroll
     for (int j = 0; j < MT; ++j)         // tile (j, blk) of inv(L); zero above the diagonal
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Lib[(long long)(16 * j + lk + 4 * r) * ld + 16 * blk + li] = y[j][r];
+        for (int r = 0; r < 4; ++r) {
+            mag += fabs(y[j][r]);
+            Lib[(long long)(16 * j + lk + 4 * r) * ld + 16 * blk + li] = y[j][r];
+        }
+    // a pivot that was not positive has made the inverse NaN or infinite: the block was not positive definite
+    if (status && !(mag < 1.0e300)) atomicOr(status + b, 2);
 }
 
 }  // namespace slamk

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "feature_kernels.hip.h"
@@ -131,6 +132,19 @@ struct ProfScope {
     }
     ~ProfScope() { if (b) (void)hipEventRecord(b, st); }
 };
+
+// Dynamic-LDS limit of a kernel, set once per (kernel, device).
+int ensure_dynamic_lds(slamk_handle* h, const void* func, size_t bytes)
+{
+    static std::vector<std::pair<const void*, int>> done;
+    int dev = 0;
+    HIPCHK(h, hipGetDevice(&dev));
+    for (const auto& d : done)
+        if (d.first == func && d.second == dev) return 0;
+    HIPCHK(h, hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done.emplace_back(func, dev);
+    return 0;
+}
 
 template <typename T>
 int dalloc(slamk_handle* h, T** p, size_t count)
@@ -306,39 +320,34 @@ Range after_predict(const Range& rg)
 
 template <int MT>
 int launch_chol_inv_block_t(slamk_handle* h, double* Sp, double* Lp, double* Lip, int ldm, long long sM, int B, int j0,
-                            hipStream_t st)
+                            int* status, hipStream_t st)
 {
     const size_t lds = ((size_t)MT * (MT + 1) / 2 + 1) * 256 * sizeof(double);
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(chol_inv_block_kernel<MT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(chol_inv_block_kernel<MT>, dim3(B), dim3(512), lds, st, Sp, Lp, Lip, ldm, sM, j0);
+    { int rc_ = ensure_dynamic_lds(h, reinterpret_cast<const void*>(chol_inv_block_kernel<MT>), lds); if (rc_) return rc_; }
+    hipLaunchKernelGGL(chol_inv_block_kernel<MT>, dim3(B), dim3(512), lds, st, Sp, Lp, Lip, ldm, sM, j0, status);
     return 0;
 }
 
 // diagonal block (nb x nb at (j0, j0), nb a multiple of 16 up to 128) of S -> L and inv(L)
 int launch_chol_inv_block(slamk_handle* h, double* Sp, double* Lp, double* Lip, int ldm, long long sM, int B, int j0,
-                          int nb, hipStream_t st)
+                          int nb, int* status, hipStream_t st)
 {
     switch (nb / 16) {
-        case 1: return launch_chol_inv_block_t<1>(h, Sp, Lp, Lip, ldm, sM, B, j0, st);
-        case 2: return launch_chol_inv_block_t<2>(h, Sp, Lp, Lip, ldm, sM, B, j0, st);
-        case 3: return launch_chol_inv_block_t<3>(h, Sp, Lp, Lip, ldm, sM, B, j0, st);
-        case 4: return launch_chol_inv_block_t<4>(h, Sp, Lp, Lip, ldm, sM, B, j0, st);
-        case 5: return launch_chol_inv_block_t<5>(h, Sp, Lp, Lip, ldm, sM, B, j0, st);
-        case 6: return launch_chol_inv_block_t<6>(h, Sp, Lp, Lip, ldm, sM, B, j0, st);
-        case 7: return launch_chol_inv_block_t<7>(h, Sp, Lp, Lip, ldm, sM, B, j0, st);
-        case 8: return launch_chol_inv_block_t<8>(h, Sp, Lp, Lip, ldm, sM, B, j0, st);
+        case 1: return launch_chol_inv_block_t<1>(h, Sp, Lp, Lip, ldm, sM, B, j0, status, st);
+        case 2: return launch_chol_inv_block_t<2>(h, Sp, Lp, Lip, ldm, sM, B, j0, status, st);
+        case 3: return launch_chol_inv_block_t<3>(h, Sp, Lp, Lip, ldm, sM, B, j0, status, st);
+        case 4: return launch_chol_inv_block_t<4>(h, Sp, Lp, Lip, ldm, sM, B, j0, status, st);
+        case 5: return launch_chol_inv_block_t<5>(h, Sp, Lp, Lip, ldm, sM, B, j0, status, st);
+        case 6: return launch_chol_inv_block_t<6>(h, Sp, Lp, Lip, ldm, sM, B, j0, status, st);
+        case 7: return launch_chol_inv_block_t<7>(h, Sp, Lp, Lip, ldm, sM, B, j0, status, st);
+        case 8: return launch_chol_inv_block_t<8>(h, Sp, Lp, Lip, ldm, sM, B, j0, status, st);
         default: return fail(h, SLAMK_EINVAL, "Cholesky diagonal block of %d rows", nb);
     }
 }
 
 // S (lower) -> L (Cholesky factor) and Li = inv(L); S is used as scratch afterwards.
 int cholesky_inverse(slamk_handle* h, double* Sp, double* Lp, double* Lip, int ldm, long long sM, int B, int ml,
-                     hipStream_t st)
+                     int* status, hipStream_t st)
 {
     const int NB = (ml <= 1024) ? 64 : 128;
     // blocked right-looking Cholesky of S (lower) into L, diagonal-block inverses into Li
@@ -346,7 +355,7 @@ int cholesky_inverse(slamk_handle* h, double* Sp, double* Lp, double* Lip, int l
         const int nb = std::min(NB, ml - j0);
         {
             ProfScope ps(h, PC_POTF2, st);
-            int rc = launch_chol_inv_block(h, Sp, Lp, Lip, ldm, sM, B, j0, nb, st);
+            int rc = launch_chol_inv_block(h, Sp, Lp, Lip, ldm, sM, B, j0, nb, status, st);
             if (rc) return rc;
         }
         const int rem = ml - j0 - nb;
@@ -390,7 +399,7 @@ int cholesky_inverse(slamk_handle* h, double* Sp, double* Lp, double* Lip, int l
 
 int run_cholesky_inverse(slamk_handle* h, const Range& rg, int ml, hipStream_t st)
 {
-    return cholesky_inverse(h, rg.S, rg.L, rg.Li, h->ldm, (long long)h->ldm * h->ldm, rg.B, ml, st);
+    return cholesky_inverse(h, rg.S, rg.L, rg.Li, h->ldm, (long long)h->ldm * h->ldm, rg.B, ml, rg.fv.status, st);
 }
 
 constexpr int SOLVER_MAX_MT = 11, SOLVER_MAX_NT = 8;
@@ -401,12 +410,7 @@ template <int MT>
 int launch_gain_solver(slamk_handle* h, const Range& rg, int nl, double* Lout, hipStream_t st)
 {
     const size_t lds = ((size_t)MT * (MT + 1) / 2 * 256 + 9 * 256) * sizeof(double);
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(gain_solver_kernel<MT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    { int rc_ = ensure_dynamic_lds(h, reinterpret_cast<const void*>(gain_solver_kernel<MT>), lds); if (rc_) return rc_; }
     const long long sM = (long long)h->ldm * h->ldm, sNM = (long long)h->ldn * h->ldm;
     hipLaunchKernelGGL(gain_solver_kernel<MT>, dim3(rg.B), dim3(512), lds, st, rg.fv, rg.W, rg.K, (double*)nullptr, Lout,
                        sM, sNM, nl / 16);
@@ -438,12 +442,7 @@ template <int NT>
 int launch_joseph(slamk_handle* h, const Range& rg, int ml, hipStream_t st)
 {
     const size_t lds = (size_t)(NT * NT + (NT <= 7 ? 2 : 1) * NT + 2) * 256 * sizeof(double);
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(joseph_kernel<NT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    { int rc_ = ensure_dynamic_lds(h, reinterpret_cast<const void*>(joseph_kernel<NT>), lds); if (rc_) return rc_; }
     hipLaunchKernelGGL(joseph_kernel<NT>, dim3(rg.B), dim3(512), lds, st, rg.fv, rg.K, h->ldm,
                        (long long)h->ldn * h->ldm, ml, h->prm.update_form, rg.dx);
     HIPCHK(h, hipGetLastError());
@@ -1059,9 +1058,11 @@ int slamk_sync(slamk_handle* h, void* stream)
     std::vector<int> st(h->B);
     HIPCHK(h, hipMemcpy(st.data(), h->fv.status, h->B * sizeof(int), hipMemcpyDeviceToHost));
     for (int b = 0; b < h->B; ++b)
-        if (st[b] & 1) {
+        if (st[b]) {
             HIPCHK(h, hipMemset(h->fv.status, 0, h->B * sizeof(int)));
-            return fail(h, SLAMK_EREFL, "filter %d: reflection rows of H, R and e disagree (zero reflection observation or innovation)", b);
+            if (st[b] & 1)
+                return fail(h, SLAMK_EREFL, "filter %d: reflection rows of H, R and e disagree (zero reflection observation or innovation)", b);
+            return fail(h, SLAMK_ENOTSPD, "filter %d: S = H P H^T + R is not positive definite (Cholesky pivot <= 0)", b);
         }
     return SLAMK_OK;
 }
@@ -1244,7 +1245,7 @@ int slamk_cholesky_inverse_dev(double* S_dev, double* L_dev, double* Li_dev, int
 {
     if (!S_dev || !L_dev || !Li_dev || m < 16 || (m & 15) || ld < m) return SLAMK_EINVAL;
     static thread_local slamk_handle scratch_handle;   // error text / profiling sink for the handle-free call
-    return cholesky_inverse(&scratch_handle, S_dev, L_dev, Li_dev, ld, (long long)ld * m, 1, m, (hipStream_t)stream);
+    return cholesky_inverse(&scratch_handle, S_dev, L_dev, Li_dev, ld, (long long)ld * m, 1, m, nullptr, (hipStream_t)stream);
 }
 
 // ---- stream pre-processing filters, batched --------------------------------------------------------------

@@ -353,6 +353,22 @@ def test_error_paths():
         fb.set_cov(0, np.eye(9))            # n must match the feature count
 
 
+@pytest.mark.parametrize("nf", [3, 60])
+def test_indefinite_innovation_covariance_is_reported(nf):
+    """A covariance that is not positive semi-definite makes S = H P H^T + R indefinite: the Cholesky gain does
+    not exist and slamk_sync says so (small fused path and blocked large path)."""
+    fb = ekf.FilterBatch(max_features=nf, batch=2)
+    q = [0, 0, 0, 1]
+    fb.frame(-1, [(i + 1, 0.05 * i - 0.1, 0.02 * i, 0, 0) for i in range(nf)], q)
+    n = 9 + 3 * nf
+    fb.set_cov(1, -50.0 * np.eye(n))
+    fb.predict(np.tile(q, 2), np.zeros(6), np.zeros(6), [0.03, 0.03])
+    with pytest.raises(ekf.SlamkError) as ei:
+        fb.update(np.tile(q, 2))
+    assert ei.value.code == _lib.SLAMK_ENOTSPD and "filter 1" in str(ei.value)
+    fb.close()
+
+
 def test_gate_rejects_mean_update_but_not_covariance():
     """main.cpp:230-232: P is updated even when sum|V - dV| >= gate."""
     st = synth.gen_stream(seed=8, nf=6, steps=4, churn=False)
