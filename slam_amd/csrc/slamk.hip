@@ -349,7 +349,7 @@ int launch_chol_inv_block(slamk_handle* h, double* Sp, double* Lp, double* Lip, 
 int cholesky_inverse(slamk_handle* h, double* Sp, double* Lp, double* Lip, int ldm, long long sM, int B, int ml,
                      int* status, hipStream_t st)
 {
-    const int NB = (ml <= 1024) ? 64 : 128;
+    const int NB = 128;
     // blocked right-looking Cholesky of S (lower) into L, diagonal-block inverses into Li
     for (int j0 = 0; j0 < ml; j0 += NB) {
         const int nb = std::min(NB, ml - j0);
@@ -1400,7 +1400,7 @@ double slamk_flops_update_stage(int n, int m, int update_form, int stage)
         return tp * 8192.0;
     }
     if (stage == 0) {
-        const int NB = (ml <= 1024) ? 64 : 128;
+        const int NB = 128;
         for (int j0 = 0; j0 < ml; j0 += NB) {
             const int nb = std::min(NB, ml - j0), rem = ml - j0 - nb;
             if (rem <= 0) break;
