@@ -405,6 +405,8 @@ int run_cholesky_inverse(slamk_handle* h, const Range& rg, int ml, hipStream_t s
 constexpr int SOLVER_MAX_MT = 11, SOLVER_MAX_NT = 8;
 
 bool use_fused_solver(int nl, int ml) { return nl <= 16 * SOLVER_MAX_NT && ml <= 16 * SOLVER_MAX_MT; }
+// the fused covariance update only needs P in LDS (and ml <= 256 for its copy of diag R)
+bool use_fused_joseph(int nl, int ml) { return nl <= 16 * SOLVER_MAX_NT && ml <= 256; }
 
 template <int MT>
 int launch_gain_solver(slamk_handle* h, const Range& rg, int nl, double* Lout, hipStream_t st)
@@ -511,7 +513,7 @@ int run_update(slamk_handle* h, const Range& rg, const double* qbw, const double
         g.C2 = rg.KR;
         HIPCHK(h, (launch_gemm<false, EPI_DUAL_COLSCALE, false, TRI_B_KGE_N>(g, B, st)));
     }
-    if (use_fused_solver(nl, ml)) {
+    if (use_fused_joseph(nl, ml)) {
         // small filters: A = I - K H, A P and the Joseph (or simple) form in one workgroup per filter
         int rc = run_joseph(h, rg, nl, ml, st);
         if (rc) return rc;
@@ -551,7 +553,7 @@ int run_update(slamk_handle* h, const Range& rg, const double* qbw, const double
     }
     ProfScope ps_tail(h, PC_FEATURE, st);
     // dx = K e, gate, mean update                (main.cpp:228-232)
-    if (!use_fused_solver(nl, ml))      // the fused covariance update has already formed dx
+    if (!use_fused_joseph(nl, ml))      // the fused covariance update has already formed dx
         hipLaunchKernelGGL(gain_kx_kernel, dim3((nl + 15) / 16, B), dim3(256), 0, st, rg.fv, rg.K, ldm, rg.dx, ml);
     hipLaunchKernelGGL(gain_apply_kernel, dim3(B), dim3(256), 0, st, rg.fv, rg.dx, applied);
     HIPCHK(h, hipGetLastError());
@@ -1383,7 +1385,7 @@ double slamk_flops_update_stage(int n, int m, int update_form, int stage)
 {
     const int nl = pad16(n), ml = pad16(m);
     double f = 0;
-    if (use_fused_solver(nl, ml)) {
+    if (stage == 0 ? use_fused_solver(nl, ml) : use_fused_joseph(nl, ml)) {
         // 16^3-tile products (2 * 16^3 flop each)
         const int MT = ml / 16, NT = nl / 16;
         double tp = 0;
