@@ -316,7 +316,7 @@ def main():
 
 
     if rank == 0:
-        # Dominant kernel: gain_solver_kernel (S = H W + R, tile Cholesky, K = W S^-1), one launch per step, timed
+        # Dominant kernel: gain_solver_kernel (W = P H^T, S = H W + R, tile Cholesky, K = W S^-1), one launch per step, timed
         # with HIP events on the launch stream.  Its algorithmic work is the 16^3 tile products it executes.
         nl, ml = (n + 15) // 16 * 16, (m + 15) // 16 * 16
         solver_ms = prof["gain_solver"][0] / K
@@ -336,8 +336,8 @@ def main():
             return None
         cov_ms = prof["gemm_cov_update"][0] / K
         cov_flops = B * ekf.flops_update_stage(n, m, 0, 1)
-        pred_ms, w_ms = prof["struct_predict"][0] / K, prof["struct_gain"][0] / K
-        pred_bytes, w_bytes = 2.0 * B * nl * nl * 8, 1.0 * B * (nl * nl + nl * ml) * 8
+        pred_ms = prof["struct_predict"][0] / K
+        pred_bytes = 2.0 * B * nl * nl * 8
         kernels = [
             {"kernel": "joseph_kernel (A = I - K H, A P, (A P) A^T + K R K^T)", "bound": "mfma", "ms": cov_ms,
              "achieved": cov_flops / (cov_ms * 1e-3) / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -345,9 +345,6 @@ def main():
             {"kernel": "predict_cov_kernel (P = F P F^T + Q, F in compact row form)", "bound": "hbm", "ms": pred_ms,
              "achieved": pred_bytes / (pred_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": pred_bytes / (pred_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_bytes("predict_cov_kernel")},
-            {"kernel": "rowsparse_right_kernel (W = P H^T, H in compact row form)", "bound": "hbm", "ms": w_ms,
-             "achieved": w_bytes / (w_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": w_bytes / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_bytes("rowsparse_right_kernel")},
         ]
         mfma_ms = solver_ms + cov_ms
         dense_flops = 8.0 * n ** 3 + 6.0 * n * n * m + 4.0 * n * m * m + m ** 3 / 3.0 + 2.0 * n * m

@@ -17,7 +17,7 @@ int main()
 {
     const int B = 4096, MT = 11, NT = 7, ldm = 208, ldn = 112;
     const long long sM = (long long)ldm * ldm, sNM = (long long)ldn * ldm;
-    std::vector<double> hW(sNM), hr(ldm), hz(ldm * 3, 0.0);
+    std::vector<double> hW((size_t)ldn * ldn), hr(ldm), hz(ldm * 3, 0.0);
     std::vector<int> hcs(ldm, -1);
     for (int i = 0; i < ldm; ++i) hr[i] = 50.0 + i;
     for (auto& x : hW) x = (double)rand() / RAND_MAX - 0.5;
@@ -25,34 +25,18 @@ int main()
     memset(&fv, 0, sizeof fv);
     fv.B = B; fv.F = 32; fv.ldn = ldn; fv.ldm = ldm;
     fv.ha = dev(hz, B); fv.hb = dev(hz, B); fv.hcs = dev(hcs, B); fv.rdiag = dev(hr, B);
-    double* W = dev(hW, B);
+    fv.P = dev(hW, B);
     double* K; hipMalloc(&K, sNM * B * 8);
-    const size_t lds = ((size_t)MT * (MT + 1) / 2 * 256 + 9 * 256) * 8;
+    const size_t lds = (size_t)SolverLds<MT>::TILES * 256 * 8;
     hipFuncSetAttribute(reinterpret_cast<const void*>(gain_solver_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-#ifdef SOLVER_STAMPS
-    const int reps = 1;      // the stamp arrays hold one launch
-#else
     const int reps = 3;
-#endif
     for (int rep = 0; rep < reps; ++rep) {
         hipEventRecord(e0);
-        gain_solver_kernel<MT><<<B, 512, lds>>>(fv, W, K, nullptr, nullptr, sM, sNM, NT);
+        gain_solver_kernel<MT><<<B, 512, lds>>>(fv, K, nullptr, nullptr, sM, sNM, NT);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("%s: %.3f ms\n", VARIANT, ms);
     }
-#ifdef SOLVER_STAMPS
-    long long st[8][128]; int ns[8];
-    hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof st);
-    hipMemcpyFromSymbol(ns, HIP_SYMBOL(g_nstamp), sizeof ns);
-    for (int w = 0; w < 8; ++w) {
-        if (w != 0 && w != 1 && w != 4) continue;
-        const int n = ns[w] < 128 ? ns[w] : 128;
-        printf("wave %d (%d stamps):", w, n);
-        for (int i = 1; i < n; ++i) printf(" %lld", st[w][i] - st[w][i - 1]);
-        printf("  total %lld\n", n > 0 ? st[w][n - 1] - st[w][0] : 0);
-    }
-#endif
     return 0;
 }

@@ -1,6 +1,6 @@
 // Fused gain solver for small filters: K = W S^-1 (and K R) from S = L L^T, one workgroup per filter.
 //
-//   in : W = P H^T  n x m, the compact rows of H, r[m] (diagonal of R); S = H W + R is formed in LDS
+//   in : P  n x n, the compact rows of H, r[m] (diagonal of R); W = P H^T and S = H W + R are formed in LDS
 //   out: K  n x m, optionally KR = K diag(r) and L (lower)
 //   m = 16 MT with MT <= 11 (the lower tiles of S, 2 KB each, live in LDS: MT (MT+1) / 2 <= 66 tiles),
 //   n = 16 NT with NT <= 8 (one wavefront per 16 columns of W^T).
@@ -23,6 +23,8 @@
 // half-wavefront.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "feature_kernels.hip.h"
 #include "gemm.hip.h"
@@ -217,15 +219,20 @@ __device__ __forceinline__ void diag_tile_factor_invert(double* t, double* xs, d
 
 // Tile Cholesky of the MT x MT lower tiles in LDS (tile (i, j) at tile_index(i, j)) together with the forward
 // solve Y^T = inv(L) B^T for up to eight 16-column blocks of B^T, one per wavefront.
-//   before: the tiles hold S, and a barrier has been passed since they were written;
+//   before: nothing (the prologue builds the S tiles);
 //   after : off-diagonal tiles hold L, diagonal tiles hold inv(L_jj), y[j] holds tile j of Y^T of the
 //           wavefront's block (accumulator layout), and a barrier has been passed.
-// init_tile(j) returns tile j of B^T for the wavefront's block.  Wavefront 0 runs the chain
+// On entry y[j] holds tile j of B^T for the block of wavefronts 1..7; wavefront 0 (an eighth block) fetches
+// its tiles with late_tile(j) after the factorisation, so that they do not occupy registers during it.
+// Wavefront 0 runs the chain
 //   L_j+1,j -> S_j+1,j+1 -> factor -> inverse   one tile column ahead of the others; per tile column two
 // barriers:  A  inv(L_jj) is in place and step j - 1 is complete;  B  the panel tiles L_ij are final.
-template <int MT, class InitTile>
+// prologue(tag) runs first in either role and leaves the S tiles in LDS (ending with a barrier); with
+// tag = std::true_type it also fills y (wavefronts 1..7), with std::false_type it must not touch y (wavefront 0):
+// the tiles of B^T are then not live across the diagonal-tile code.
+template <int MT, class Prologue, class LateTile>
 __device__ __forceinline__ void tile_cholesky_forward(double* lds, v4d (&y)[MT], bool has_blk, double* Lb, int ldl,
-                                                      int wave, int lane, InitTile init_tile)
+                                                      int wave, int lane, Prologue prologue, LateTile late_tile)
 {
     constexpr int NTILES = MT * (MT + 1) / 2;
     const int li = lane & 15, lk = lane >> 4;
@@ -255,6 +262,7 @@ __device__ __forceinline__ void tile_cholesky_forward(double* lds, v4d (&y)[MT],
     };
 
     if (wave == 0) {
+        prologue(std::false_type{});
         diag_tile_factor_invert(lds, lds + NTILES * 256, Lb, ldl, lane);
         for (int j = 0; j < MT; ++j) {
             __syncthreads();                             // A
@@ -269,11 +277,10 @@ __device__ __forceinline__ void tile_cholesky_forward(double* lds, v4d (&y)[MT],
         __syncthreads();
         if (has_blk) {                                   // an eighth block: its forward solve runs here
 #pragma unroll
-            for (int j = 0; j < MT; ++j) y[j] = forward_step(j, init_tile(j));
+            for (int j = 0; j < MT; ++j) y[j] = forward_step(j, late_tile(j));
         }
     } else {
-#pragma unroll
-        for (int j = 0; j < MT; ++j) y[j] = init_tile(j);
+        prologue(std::true_type{});
         // Wavefront 4 shares its SIMD with wavefront 0: it stays out of the factorisation loop, where that SIMD
         // belongs to the diagonal-tile chain, and runs its forward solve afterwards, when wavefront 0 is idle.
         const int wk6 = wave < 4 ? wave - 1 : wave - 2;  // 0..5 for wavefronts 1 2 3 5 6 7
@@ -324,16 +331,25 @@ __device__ __forceinline__ void store_offdiag_tiles(const double* lds, double* L
     }
 }
 
+// LDS beyond the S tiles: scratch tile of the diagonal-tile routine + eight per-wavefront staging tiles during
+// and after the factorisation; before it, the compact rows of H and one 16-column panel of W = P H^T.
 template <int MT>
-__global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, const double* __restrict__ W,
-                                                           double* __restrict__ K, double* __restrict__ KR,
+struct SolverLds {
+    static constexpr int M = 16 * MT;
+    static constexpr int COEF_TILES = (15 * M / 2 + 255) / 256;          // ha, hb [M][3], r [M], cs [M] (int)
+    static constexpr int EXTRA_TILES = (COEF_TILES + 8 > 9) ? COEF_TILES + 8 : 9;
+    static constexpr int TILES = MT * (MT + 1) / 2 + EXTRA_TILES;
+};
+
+template <int MT>
+__global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double* __restrict__ K, double* __restrict__ KR,
                                                            double* __restrict__ L, long long sM, long long sNM, int NT)
 {
-    extern __shared__ double lds[];                     // MT (MT + 1) / 2 tiles of 256 doubles + 9 scratch tiles
+    extern __shared__ double lds[];                     // SolverLds<MT>::TILES tiles of 256 doubles
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const int ldm = fv.ldm;
+    const int ldm = fv.ldm, ldn = fv.ldn;
     double* Lb = L ? L + (long long)b * sM : nullptr;
     constexpr int NTILES = MT * (MT + 1) / 2;
     constexpr int M = 16 * MT;
@@ -341,60 +357,98 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, const d
     // block 7 when there is one), so the solves run beside the factorisation.
     const int blk = (wave + 7) & 7;
     const bool has_blk = blk < NT;
-    double* stg = lds + (NTILES + 1 + wave) * 256;      // per-wavefront staging tile
-    const double* Wf = W + (long long)b * sNM;
+    const int nl = 16 * NT;
+    double* scratch = lds + NTILES * 256;
+    double* stg = scratch + (1 + wave) * 256;           // per-wavefront staging tile (after the build phase)
     const double* rd = fv.rdiag + (long long)b * ldm;
+    const double* Pb = fv.P + (long long)b * ldn * ldn;
 
-    // ---- S = H W + R (calcK, src/slam/main.cpp:541-543), lower tiles, straight into LDS --------------------
-    // Row q of H has entries on columns 0..2 and cs_q..cs_q+2 only, so S[q][q'] is six products with rows of W.
-    // The compact rows of H are staged in the (still unused) staging tiles first.
+    // ---- W = P H^T (calcK, src/slam/main.cpp:545) one 16-column panel at a time, and from each panel the tiles
+    //      of S = H W + R (:541-543) below the diagonal and the wavefronts' tiles of W^T.  Row q of H has entries on
+    //      columns 0..2 and cs_q..cs_q+2 only: six products per element of W and of S.  Neither W nor S exists in HBM.
+    double* cha = scratch;                               // [M][3]
+    double* chb = cha + 3 * M;                           // [M][3]
+    double* crd = chb + 3 * M;                           // [M]
+    int* ccs = reinterpret_cast<int*>(crd + M);          // [M]
+    double* pan = scratch + SolverLds<MT>::COEF_TILES * 256;   // NT tiles: rows of W, 16 columns
     {
-        double* cha = lds + (NTILES + 1) * 256;          // [M][3]
-        double* chb = cha + 3 * M;                       // [M][3]
-        double* crd = chb + 3 * M;                       // [M]
-        int* ccs = reinterpret_cast<int*>(crd + M);      // [M]
         const long long rb = (long long)b * ldm;
         for (int t = tid; t < 3 * M; t += 512) { cha[t] = fv.ha[rb * 3 + t]; chb[t] = fv.hb[rb * 3 + t]; }
         for (int t = tid; t < M; t += 512) { crd[t] = rd[t]; ccs[t] = fv.hcs[rb + t]; }
-        __syncthreads();
-        for (int t = wave; t < NTILES; t += 8) {
-            int i = 0;
-            while ((i + 1) * (i + 2) / 2 <= t) ++i;
-            const int j = t - i * (i + 1) / 2;
-            double* tl = lds + t * 256;
-            const int qc = 16 * j + li;
-            const double x0 = Wf[qc], x1 = Wf[ldm + qc], x2 = Wf[2 * ldm + qc];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = lk + 4 * r, q = 16 * i + row;
-                const int cs = max(ccs[q], 0);
-                const double* wr = Wf + (long long)cs * ldm + qc;
-                double v = cha[3 * q] * x0;
-                v = fma(cha[3 * q + 1], x1, v);
-                v = fma(cha[3 * q + 2], x2, v);
-                v = fma(chb[3 * q], wr[0], v);
-                v = fma(chb[3 * q + 1], wr[ldm], v);
-                v = fma(chb[3 * q + 2], wr[2 * ldm], v);
-                if (q == qc) v += crd[q];
-                tl[tsw(row, li)] = v;
-            }
-        }
     }
     __syncthreads();
+    v4d y[MT];
+    double* Kpark = K + (long long)b * sNM + (long long)(16 * blk) * ldm;
+    auto build = [&](auto with_y) {
+        const int ec = tid & 15, ea = tid >> 4;          // panel column, row within a group of 32 rows
+        double px[4][3], pf[4][3];                       // P[a][0..2] once, P[a][cs..cs+2] per panel
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double* row = Pb + (long long)min(ea + 32 * u, nl - 1) * ldn;
+            px[u][0] = row[0]; px[u][1] = row[1]; px[u][2] = row[2];
+        }
+        auto load_panel = [&](int j) {                   // the entries of P in the observed feature's columns
+            const int cs = max(ccs[16 * j + ec], 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double* row = Pb + (long long)min(ea + 32 * u, nl - 1) * ldn + cs;
+                pf[u][0] = row[0]; pf[u][1] = row[1]; pf[u][2] = row[2];
+            }
+        };
+        load_panel(0);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            {
+                const int q = 16 * j + ec;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int a = ea + 32 * u;
+                    double v = px[u][0] * cha[3 * q];
+                    v = fma(px[u][1], cha[3 * q + 1], v);
+                    v = fma(px[u][2], cha[3 * q + 2], v);
+                    v = fma(pf[u][0], chb[3 * q], v);
+                    v = fma(pf[u][1], chb[3 * q + 1], v);
+                    v = fma(pf[u][2], chb[3 * q + 2], v);
+                    if (a < nl) pan[(a >> 4) * 256 + tsw(a & 15, ec)] = v;
+                }
+            }
+            if (j + 1 < MT) load_panel(j + 1);           // in flight while this panel is consumed
+            __syncthreads();
+            for (int i = j + wave; i < MT; i += 8) {     // S tiles (i, j), i >= j
+                double* tl = lds + tile_index(i, j) * 256;
+                const double x0 = pan[tsw(0, li)], x1 = pan[tsw(1, li)], x2 = pan[tsw(2, li)];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = lk + 4 * r, q = 16 * i + row;
+                    const int cs = max(ccs[q], 0);
+                    double v = cha[3 * q] * x0;
+                    v = fma(cha[3 * q + 1], x1, v);
+                    v = fma(cha[3 * q + 2], x2, v);
+                    v = fma(chb[3 * q], pan[(cs >> 4) * 256 + tsw(cs & 15, li)], v);
+                    v = fma(chb[3 * q + 1], pan[((cs + 1) >> 4) * 256 + tsw((cs + 1) & 15, li)], v);
+                    v = fma(chb[3 * q + 2], pan[((cs + 2) >> 4) * 256 + tsw((cs + 2) & 15, li)], v);
+                    if (q == 16 * j + li) v += crd[q];
+                    tl[tsw(row, li)] = v;
+                }
+            }
+            if (has_blk) {                               // tile (blk, j) of W, transposed: accumulator layout of W^T
+                if constexpr (decltype(with_y)::value) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[j][r] = pan[blk * 256 + tsw(li, lk + 4 * r)];
+                } else {                                 // parked in this block's rows of K until the factorisation is done
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Kpark[(long long)li * ldm + 16 * j + lk + 4 * r] = pan[blk * 256 + tsw(li, lk + 4 * r)];
+                }
+            }
+            __syncthreads();
+        }
+    };
 
     // ---- factorisation and Y^T = inv(L) W^T ------------------------------------------------------------------
-    // tile (blk, j) of W: rows read as 128-byte runs, transposed through the wavefront's staging tile
-    const double* Wb = Wf + (long long)(16 * (has_blk ? blk : 0) + lk) * ldm + li;
-    v4d y[MT];
-    tile_cholesky_forward<MT>(lds, y, has_blk, Lb, ldm, wave, lane, [&](int j) {
-        double g[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) g[r] = Wb[(long long)(4 * r) * ldm + 16 * j];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) stg[tsw(lk + 4 * r, li)] = g[r];
+    tile_cholesky_forward<MT>(lds, y, has_blk, Lb, ldm, wave, lane, build, [&](int j) {
         v4d t;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) t[r] = stg[tsw(li, lk + 4 * r)];
+        for (int r = 0; r < 4; ++r) t[r] = Kpark[(long long)li * ldm + 16 * j + lk + 4 * r];
         return t;
     });
     if (Lb) store_offdiag_tiles<MT>(lds, Lb, ldm, wave, lane);
@@ -408,7 +462,7 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, const d
         for (int k = j + 1; k < MT; ++k) acc = tile_mma_regB<true, true>(lds + tile_index(k, j) * 256, y[k], acc, li, lk);
         y[j] = tile_mma_regB<true, false>(lds + tile_index(j, j) * 256, acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
     }
-    // K tiles leave through the staging tile as well: 128-byte runs per row
+    // K tiles leave through the wavefront's staging tile: 128-byte runs per row
     double* Kb = K + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li;
     double* KRb = KR ? KR + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li : nullptr;
     double mag = 0.0;                                    // a pivot that was not positive has made K NaN or infinite
@@ -445,22 +499,30 @@ __global__ void __launch_bounds__(512) chol_inv_block_kernel(const double* __res
     double* Lib = Li + o;
     const int blk = (wave + 7) & 7;
     const bool has_blk = blk < MT;
-    for (int t = wave; t < MT * (MT + 1) / 2; t += 8) {
-        int i = 0;
-        while ((i + 1) * (i + 2) / 2 <= t) ++i;
-        const int j = t - i * (i + 1) / 2;
-        double* tl = lds + t * 256;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = lk + 4 * r;
-            // the diagonal tiles are completed from their lower triangle
-            const int rr = (i == j && li > row) ? li : row, cc = (i == j && li > row) ? row : li;
-            tl[tsw(row, li)] = Sb[(long long)(16 * i + rr) * ld + 16 * j + cc];
-        }
-    }
-    __syncthreads();
     v4d y[MT];
-    tile_cholesky_forward<MT>(lds, y, has_blk, Lb, ld, wave, lane, [&](int j) {
+    auto load = [&](auto with_y) {
+        for (int t = wave; t < MT * (MT + 1) / 2; t += 8) {
+            int i = 0;
+            while ((i + 1) * (i + 2) / 2 <= t) ++i;
+            const int j = t - i * (i + 1) / 2;
+            double* tl = lds + t * 256;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = lk + 4 * r;
+                // the diagonal tiles are completed from their lower triangle
+                const int rr = (i == j && li > row) ? li : row, cc = (i == j && li > row) ? row : li;
+                tl[tsw(row, li)] = Sb[(long long)(16 * i + rr) * ld + 16 * j + cc];
+            }
+        }
+        if constexpr (decltype(with_y)::value) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[j][r] = (j == blk && lk + 4 * r == li) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+    };
+    tile_cholesky_forward<MT>(lds, y, has_blk, Lb, ld, wave, lane, load, [&](int j) {
         v4d t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) t[r] = (j == blk && lk + 4 * r == li) ? 1.0 : 0.0;

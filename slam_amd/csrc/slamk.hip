@@ -411,11 +411,11 @@ bool use_fused_joseph(int nl, int ml) { return nl <= 16 * SOLVER_MAX_NT && ml <=
 template <int MT>
 int launch_gain_solver(slamk_handle* h, const Range& rg, int nl, double* Lout, hipStream_t st)
 {
-    const size_t lds = ((size_t)MT * (MT + 1) / 2 * 256 + 9 * 256) * sizeof(double);
+    const size_t lds = (size_t)SolverLds<MT>::TILES * 256 * sizeof(double);
     { int rc_ = ensure_dynamic_lds(h, reinterpret_cast<const void*>(gain_solver_kernel<MT>), lds); if (rc_) return rc_; }
     const long long sM = (long long)h->ldm * h->ldm, sNM = (long long)h->ldn * h->ldm;
-    hipLaunchKernelGGL(gain_solver_kernel<MT>, dim3(rg.B), dim3(512), lds, st, rg.fv, rg.W, rg.K, (double*)nullptr, Lout,
-                       sM, sNM, nl / 16);
+    hipLaunchKernelGGL(gain_solver_kernel<MT>, dim3(rg.B), dim3(512), lds, st, rg.fv, rg.K, (double*)nullptr, Lout, sM, sNM,
+                       nl / 16);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -490,11 +490,12 @@ int run_update(slamk_handle* h, const Range& rg, const double* qbw, const double
     const RowSparse MH{rg.fv.ha, rg.fv.hb, rg.fv.hcs, ldm, 0};
     {
     ProfScope ps(h, PC_STRUCT_GAIN, st);
-    // W = P H^T                                  (calcK, src/slam/main.cpp:545)
-    launch_right(MH, rg.fv.P, ldn, sN, rg.W, ldm, sNM, nl, ml, B, st);
-    // S = H W + R, lower part                    (:541-543); the fused solver forms it in LDS itself
-    if (!use_fused_solver(nl, ml))
+    if (!use_fused_solver(nl, ml)) {     // the fused solver forms W and S in LDS itself
+        // W = P H^T                                  (calcK, src/slam/main.cpp:545)
+        launch_right(MH, rg.fv.P, ldn, sN, rg.W, ldm, sNM, nl, ml, B, st);
+        // S = H W + R, lower part                    (:541-543)
         launch_left<true>(MH, rg.W, ldm, sNM, rg.S, ldm, sM, rg.fv.rdiag, ldm, ml, ml, B, st);
+    }
     }
     if (use_fused_solver(nl, ml)) {
         // small filters: S = L L^T and K = W L^-T L^-1 (plus K R) in one workgroup per filter
