@@ -65,7 +65,11 @@ typedef struct {
 
 void slamk_default_params(slamk_params* p);
 
-/* Allocates device state and workspaces for `batch` filters on HIP device `device`.
+/* Allocates device state for `batch` filters on HIP device `device`: per filter the covariance twice
+ * (ldn^2), the gain (ldn x ldm) and O(max_features) vectors, ldn = 9 + 3 max_features and ldm = 1 + 6 max_features
+ * rounded up to 16.  Filters small enough for the per-filter kernels (n <= 128, m <= 176) never need more; the
+ * first predict/update/step/set_debug call that meets a larger layout (or debug mode) allocates the GEMM-path
+ * workspaces (about 3 ldm^2 + 3 ldn ldm + 2 ldn^2 doubles per filter) and synchronises the device once.
  * Every filter starts like main() does: X=V=bias=0, no features,
  * P = diag(pinit x3, 1 x3, pinit x3)  (src/slam/main.cpp:121-123,130). */
 int slamk_create(const slamk_params* p, int max_features, int batch, int device, slamk_handle** out);

@@ -60,6 +60,7 @@ struct slamk_handle {
     int *slots_d = nullptr;               // [F] slots of new features
     double *sxy_d = nullptr;              // [F][2] their first observations
     std::vector<void*> allocs;
+    int have_ws = 0;                      // WS_* groups allocated so far (ensure_workspaces)
     std::string err;
     hipStream_t stream = nullptr;
     int last_nl = 0, last_ml = 0;
@@ -168,6 +169,42 @@ int max_ml(const slamk_handle* h)
     int m = 1;
     for (const auto& f : h->hf) m = std::max(m, f.m());
     return pad16(m);
+}
+
+constexpr int SOLVER_MAX_MT = 11, SOLVER_MAX_NT = 8;
+
+bool use_fused_solver(int nl, int ml) { return nl <= 16 * SOLVER_MAX_NT && ml <= 16 * SOLVER_MAX_MT; }
+// the fused covariance update only needs P in LDS (and ml <= 256 for its copy of diag R)
+bool use_fused_joseph(int nl, int ml) { return nl <= 16 * SOLVER_MAX_NT && ml <= 256; }
+
+// Workspaces beyond P, T and K.  The per-filter fused kernels keep every intermediate in LDS, so a batch of small
+// filters never touches these: they are allocated when a layout or the debug switch first needs them.
+enum { WS_GAIN = 1,     // W, Y, KR, S, L, Li: gain by blocked Cholesky + GEMMs
+       WS_COV = 2,      // Am, AP: covariance update by GEMMs
+       WS_DENSE = 4 };  // Fm, Hm (and L): dense Jacobians and the factor for slamk_debug_get*
+
+int ensure_workspaces(slamk_handle* h)
+{
+    const int nl = max_nl(h), ml = max_ml(h);
+    int need = 0;
+    if (!use_fused_solver(nl, ml)) need |= WS_GAIN;
+    if (!use_fused_joseph(nl, ml)) need |= WS_COV;
+    if (h->debug) need |= WS_DENSE;
+    need &= ~h->have_ws;
+    if (!need) return 0;
+    const size_t B = h->B, ldn = h->ldn, ldm = h->ldm;
+    int rc = 0;
+    if ((need & (WS_GAIN | WS_DENSE)) && !h->L) rc |= dalloc(h, &h->L, B * ldm * ldm);
+    if (need & WS_GAIN) {
+        rc |= dalloc(h, &h->W, B * ldn * ldm); rc |= dalloc(h, &h->Y, B * ldn * ldm); rc |= dalloc(h, &h->KR, B * ldn * ldm);
+        rc |= dalloc(h, &h->S, B * ldm * ldm); rc |= dalloc(h, &h->Li, B * ldm * ldm);
+    }
+    if (need & WS_COV) { rc |= dalloc(h, &h->Am, B * ldn * ldn); rc |= dalloc(h, &h->AP, B * ldn * ldn); }
+    if (need & WS_DENSE) { rc |= dalloc(h, &h->Fm, B * ldn * ldn); rc |= dalloc(h, &h->Hm, B * ldm * ldn); }
+    if (rc) return SLAMK_EHIP;
+    HIPCHK(h, hipDeviceSynchronize());          // the zero fill is complete before any stream uses the buffers
+    h->have_ws |= need;
+    return 0;
 }
 
 GemmArgs gargs(const double* A, int lda, long long sA, const double* Bp, int ldb, long long sB, double* C, int ldc,
@@ -280,10 +317,11 @@ Range make_range(const slamk_handle* h, int b0, int cnt)
     v.ha += 3 * ldm * o; v.hb += 3 * ldm * o; v.hcs += ldm * o;
     v.e += ldm * o; v.rdiag += ldm * o; v.qdiag += ldn * o;
     v.fa += 3 * ldn * o; v.fg += 3 * ldn * o; v.fgs += ldn * o;
-    r.T = h->T + ldn * ldn * o; r.Am = h->Am + ldn * ldn * o; r.AP = h->AP + ldn * ldn * o; r.Fm = h->Fm + ldn * ldn * o;
-    r.Hm = h->Hm + ldm * ldn * o;
-    r.W = h->W + ldn * ldm * o; r.K = h->K + ldn * ldm * o; r.KR = h->KR + ldn * ldm * o; r.Y = h->Y + ldn * ldm * o;
-    r.S = h->S + ldm * ldm * o; r.L = h->L + ldm * ldm * o; r.Li = h->Li + ldm * ldm * o;
+    auto at = [](double* p, size_t off) { return p ? p + off : nullptr; };      // workspaces may not exist yet
+    r.T = h->T + ldn * ldn * o; r.Am = at(h->Am, ldn * ldn * o); r.AP = at(h->AP, ldn * ldn * o);
+    r.Fm = at(h->Fm, ldn * ldn * o); r.Hm = at(h->Hm, ldm * ldn * o);
+    r.W = at(h->W, ldn * ldm * o); r.K = h->K + ldn * ldm * o; r.KR = at(h->KR, ldn * ldm * o); r.Y = at(h->Y, ldn * ldm * o);
+    r.S = at(h->S, ldm * ldm * o); r.L = at(h->L, ldm * ldm * o); r.Li = at(h->Li, ldm * ldm * o);
     r.dx = h->dx + ldn * o;
     return r;
 }
@@ -401,12 +439,6 @@ int run_cholesky_inverse(slamk_handle* h, const Range& rg, int ml, hipStream_t s
 {
     return cholesky_inverse(h, rg.S, rg.L, rg.Li, h->ldm, (long long)h->ldm * h->ldm, rg.B, ml, rg.fv.status, st);
 }
-
-constexpr int SOLVER_MAX_MT = 11, SOLVER_MAX_NT = 8;
-
-bool use_fused_solver(int nl, int ml) { return nl <= 16 * SOLVER_MAX_NT && ml <= 16 * SOLVER_MAX_MT; }
-// the fused covariance update only needs P in LDS (and ml <= 256 for its copy of diag R)
-bool use_fused_joseph(int nl, int ml) { return nl <= 16 * SOLVER_MAX_NT && ml <= 256; }
 
 template <int MT>
 int launch_gain_solver(slamk_handle* h, const Range& rg, int nl, double* Lout, hipStream_t st)
@@ -661,12 +693,8 @@ int slamk_create(const slamk_params* p, int max_features, int batch, int device,
     rc |= dalloc(h, &v.ha, B * ldm * 3); rc |= dalloc(h, &v.hb, B * ldm * 3); rc |= dalloc(h, &v.hcs, B * ldm);
     rc |= dalloc(h, &v.e, B * ldm); rc |= dalloc(h, &v.rdiag, B * ldm); rc |= dalloc(h, &v.qdiag, B * ldn);
     rc |= dalloc(h, &v.fa, B * ldn * 3); rc |= dalloc(h, &v.fg, B * ldn * 3); rc |= dalloc(h, &v.fgs, B * ldn);
-    rc |= dalloc(h, &h->Fm, B * ldn * ldn); rc |= dalloc(h, &h->T, B * ldn * ldn);
-    rc |= dalloc(h, &h->Am, B * ldn * ldn); rc |= dalloc(h, &h->AP, B * ldn * ldn);
-    rc |= dalloc(h, &h->Hm, B * ldm * ldn);
-    rc |= dalloc(h, &h->W, B * ldn * ldm); rc |= dalloc(h, &h->Y, B * ldn * ldm);
-    rc |= dalloc(h, &h->K, B * ldn * ldm); rc |= dalloc(h, &h->KR, B * ldn * ldm);
-    rc |= dalloc(h, &h->S, B * ldm * ldm); rc |= dalloc(h, &h->L, B * ldm * ldm); rc |= dalloc(h, &h->Li, B * ldm * ldm);
+    rc |= dalloc(h, &h->T, B * ldn * ldn);
+    rc |= dalloc(h, &h->K, B * ldn * ldm);
     rc |= dalloc(h, &h->dx, B * ldn);
     rc |= dalloc(h, &h->qbw_d, B * 4); rc |= dalloc(h, &h->w_d, B * 3); rc |= dalloc(h, &h->acc_d, B * 3);
     rc |= dalloc(h, &h->dt_d, B); rc |= dalloc(h, &h->alt_d, B); rc |= dalloc(h, &h->applied_d, B);
@@ -677,10 +705,8 @@ int slamk_create(const slamk_params* p, int max_features, int batch, int device,
     v.inv_dmax = 1 / h->prm.d_max; v.inv_dmin = 1 / h->prm.d_min;
     v.alt_override = h->prm.alt_override; v.use_alt_override = h->prm.use_alt_override;
     hipLaunchKernelGGL(init_cov_kernel, dim3(batch), dim3(64), 0, 0, v.P, h->ldn, (long long)ldn * ldn, h->prm.pinit);
-    for (int b = 0; b < batch; ++b) {
-        int one = 1;
-        HIPCHK(h, hipMemcpy(v.m + b, &one, sizeof(int), hipMemcpyHostToDevice));
-    }
+    const std::vector<int> ones(batch, 1);      // m = 1: the altitude row
+    HIPCHK(h, hipMemcpy(v.m, ones.data(), ones.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(h, hipDeviceSynchronize());
     return SLAMK_OK;
 }
@@ -695,6 +721,8 @@ int slamk_destroy(slamk_handle* h)
     for (auto g : h->gstreams) (void)hipStreamDestroy(g);
     for (auto e : h->gdone) (void)hipEventDestroy(e);
     if (h->fork) (void)hipEventDestroy(h->fork);
+    for (auto& r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : h->prof_pool) (void)hipEventDestroy(e);
     delete h;
     return SLAMK_OK;
 }
@@ -976,6 +1004,7 @@ int slamk_predict_dev(slamk_handle* h, const double* qbw_dev, const double* w_de
 {
     if (!h || !qbw_dev || !w_dev || !acc_dev || !dt_dev) return SLAMK_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    { int rc_ = ensure_workspaces(h); if (rc_) return rc_; }
     int rc = run_predict(h, make_range(h, 0, h->B), qbw_dev, w_dev, acc_dev, dt_dev, (hipStream_t)stream);
     std::swap(h->fv.P, h->T);          // T is whichever of the two covariance-sized buffers is not P
     return rc;
@@ -987,6 +1016,7 @@ int slamk_update_dev(slamk_handle* h, const double* qbw_dev, const double* alt_d
     if (!h || !qbw_dev) return SLAMK_EINVAL;
     if (!alt_dev && !h->prm.use_alt_override) return fail(h, SLAMK_EINVAL, "update: alt required without alt_override");
     HIPCHK(h, hipSetDevice(h->device));
+    { int rc_ = ensure_workspaces(h); if (rc_) return rc_; }
     return run_update(h, make_range(h, 0, h->B), qbw_dev, alt_dev ? alt_dev : h->alt_d, src_dev, refl_dev, applied_dev,
                       (hipStream_t)stream);
 }
@@ -1002,6 +1032,7 @@ int slamk_step_dev(slamk_handle* h, const double* qbw_dev, const double* w_dev, 
     if (!h || !qbw_dev || !w_dev || !acc_dev || !dt_dev) return SLAMK_EINVAL;
     if (!alt_dev && !h->prm.use_alt_override) return fail(h, SLAMK_EINVAL, "step: alt required without alt_override");
     HIPCHK(h, hipSetDevice(h->device));
+    { int rc_ = ensure_workspaces(h); if (rc_) return rc_; }
     hipStream_t st = (hipStream_t)stream;
     if (h->graph_mode && !h->prof_on && st != nullptr) {
         // replay (or first capture) the launch sequence as one hipGraph: one submission per iteration
@@ -1074,6 +1105,7 @@ int slamk_predict(slamk_handle* h, const double* qbw, const double* w, const dou
 {
     if (!h || !qbw || !w || !acc || !dt) return SLAMK_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    { int rc_ = ensure_workspaces(h); if (rc_) return rc_; }
     const size_t B = h->B;
     HIPCHK(h, hipMemcpy(h->qbw_d, qbw, B * 32, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->w_d, w, B * 24, hipMemcpyHostToDevice));
@@ -1091,6 +1123,7 @@ int slamk_update(slamk_handle* h, const double* qbw, const double* alt, int* app
     if (!h || !qbw) return SLAMK_EINVAL;
     if (!alt && !h->prm.use_alt_override) return fail(h, SLAMK_EINVAL, "update: alt required without alt_override");
     HIPCHK(h, hipSetDevice(h->device));
+    { int rc_ = ensure_workspaces(h); if (rc_) return rc_; }
     const size_t B = h->B;
     HIPCHK(h, hipMemcpy(h->qbw_d, qbw, B * 32, hipMemcpyHostToDevice));
     if (alt) HIPCHK(h, hipMemcpy(h->alt_d, alt, B * 8, hipMemcpyHostToDevice));
@@ -1107,6 +1140,7 @@ int slamk_stage_motion_dev(slamk_handle* h, const double* qbw_dev, const double*
 {
     if (!h || !qbw_dev || !w_dev || !acc_dev || !dt_dev) return SLAMK_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    { int rc_ = ensure_workspaces(h); if (rc_) return rc_; }
     hipStream_t st = (hipStream_t)stream;
     const int nl = max_nl(h);
     hipLaunchKernelGGL(motion_rows_kernel, dim3((nl + 255) / 256, h->B), dim3(256), 0, st, h->fv, qbw_dev, w_dev, dt_dev, nl);
@@ -1123,6 +1157,7 @@ int slamk_stage_measure_dev(slamk_handle* h, const double* qbw_dev, const double
 {
     if (!h || !qbw_dev) return SLAMK_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    { int rc_ = ensure_workspaces(h); if (rc_) return rc_; }
     hipStream_t st = (hipStream_t)stream;
     const int nl = max_nl(h), ml = max_ml(h);
     int nfmax = 0;
@@ -1286,8 +1321,9 @@ int slamk_pre_fir_dev(const double* coeffs_dev, int order, const double* x_dev, 
 int slamk_set_debug(slamk_handle* h, int on)
 {
     if (!h) return SLAMK_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
     h->debug = on != 0;
-    return SLAMK_OK;
+    return ensure_workspaces(h);
 }
 
 int slamk_debug_get(slamk_handle* h, int b, double* H, double* L, double* K, double* e)
