@@ -314,6 +314,16 @@ def main():
     stream.synchronize()
     t_predict = (time.perf_counter() - tp0) / K
 
+    # the boundary's host-pointer entry points (PCIe copies of the per-filter sensor inputs + host synchronisation
+    # in every call); the observations are the ones kept from the last frame.  Reported beside `value`, never as it.
+    hk = min(K, 5)
+    hsteps = [{k: v.cpu().numpy() for k, v in steps[W + i].items() if k in ("qbw", "w", "acc", "dt")} for i in range(hk)]
+    torch.cuda.synchronize(dev)
+    th0 = time.perf_counter()
+    for hs in hsteps:
+        fb.predict(hs["qbw"], hs["w"], hs["acc"], hs["dt"])
+        fb.update(hs["qbw"])
+    t_host = (time.perf_counter() - th0) / hk
 
     if rank == 0:
         # Dominant kernel: gain_solver_kernel (W = P H^T, S = H W + R, tile Cholesky, K = W S^-1), one launch per step, timed
@@ -375,6 +385,8 @@ def main():
             "dense_model": {"flops_per_update": dense_flops, "equivalent_tflops": world * B * K / t * dense_flops / 1e12 / world,
                             "equivalent_frac_of_fp64_matrix_peak": B * K / t * dense_flops / 1e12 / FP64_MATRIX_PEAK_TFLOPS},
             "predict_only": {"ms_per_step": t_predict * 1e3, "predicts_per_s": world * B / t_predict},
+            "host_boundary": {"entry_points": "slamk_predict + slamk_update (host pointers, PCIe-inclusive, synchronous)",
+                              "ms_per_step": t_host * 1e3, "updates_per_s": B / t_host, "steps": hk},
             "stages_ms_per_step": {k: round(v[0] / K, 4) for k, v in prof.items()},
             "outputs_sane": sane,
         }

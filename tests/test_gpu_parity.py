@@ -100,6 +100,20 @@ def test_fused_path_tile_count_edges(nf, ref_fraction, form):
     print("nf=%d ref=%.1f form=%d worst rel err %.2e" % (nf, ref_fraction, form, worst))
 
 
+def test_map_growing_through_every_path_in_one_handle():
+    """One handle whose map grows 30 -> 37 -> 45 features: per-filter kernels, then the GEMM gain with the fused
+    covariance update, then the all-GEMM path; the larger paths' workspaces first appear in the middle of the run."""
+    st = synth.gen_stream(seed=91, nf=30, steps=46, churn=False, ref_fraction=0.5, add_at=15, add_count=7)
+    st2 = synth.gen_stream(seed=91, nf=30, steps=46, churn=False, ref_fraction=0.5, add_at=15, add_count=15)
+    for stream, nf_end in ((st, 37), (st2, 45)):
+        so, _ = helpers.run_oracle(stream)
+        fb = ekf.FilterBatch(max_features=48, batch=1)
+        sg = helpers.run_gpu(stream, fb)
+        assert len(sg[-1]["ids"]) == nf_end
+        worst = compare_snaps(so, sg)
+        print("30 -> %d features: worst rel err %.2e" % (nf_end, worst))
+
+
 def test_per_function_parity():
     """F, H, innovation, Cholesky factor and gain of one step against the oracle's functions."""
     st = synth.gen_stream(seed=4, nf=14, steps=7, churn=False)
