@@ -166,7 +166,7 @@ int slamk_stage_measure_dev(slamk_handle* h, const double* qbw_dev, const double
  *   right: Out[rows x mrows] = In[rows x n] * M^T                      (T_r = P_r F^T, W_r = P_r H^T)
  *   left : Out[rows x cols]  = M[row0 .. row0+rows, :] * In[n x cols]  (+ diag Q / R on the operator's diagonal)
  *   eye_minus_kh: A[rows x n] = I[row0 .., :] - K[rows x m] H          (src/slam/main.cpp:563-565)
- *   gain : Y = W Li^T, K = Y Li, KR = K diag(r) for a row block of W   (src/slam/main.cpp:545-550)
+ *   gain : K = W S^-1 by two block triangular solves, KR = K diag(r), for a row block of W (overwritten)   (src/slam/main.cpp:545-550)
  * Rows past the operator (padding of a row-block layout) are not written. */
 int slamk_stage_right_dev(slamk_handle* h, int which, const double* In_dev, int ldi, int rows, double* Out_dev, int ldo,
                           void* stream);
@@ -174,15 +174,17 @@ int slamk_stage_left_dev(slamk_handle* h, int which, int row0, int rows, const d
                          double* Out_dev, int ldo, int add_diag, void* stream);
 int slamk_stage_eye_minus_kh_dev(slamk_handle* h, const double* K_dev, int ldk, int row0, int rows, double* A_dev,
                                  int lda, void* stream);
-int slamk_stage_gain_dev(slamk_handle* h, const double* W_dev, int rows, int m, int ld, const double* Li_dev, int ldli,
-                         double* Y_dev, double* K_dev, double* KR_dev, const double* r_dev, void* stream);
+int slamk_stage_gain_dev(slamk_handle* h, double* W_dev, int rows, int m, int ld, const double* L_dev,
+                         const double* Li_dev, int ldli, double* Y_dev, double* K_dev, double* KR_dev,
+                         const double* r_dev, void* stream);
 /* dx = K e with the caller's gain K (n x m, leading dimension ldk), gate and mean update (main.cpp:228-232). */
 int slamk_stage_apply_dev(slamk_handle* h, const double* K_dev, int ldk, int32_t* applied_dev, void* stream);
 /* Device address and shape of one of the handle's matrices (filter 0): which = 0 F, 1 H, 2 innovation e,
  * 3 diag R, 4 diag Q, 5 P.  rows/cols are the padded live dimensions, ld the leading dimension. */
 int slamk_buffer_dev(slamk_handle* h, int which, double** ptr, int* rows, int* cols, int* ld);
-/* Cholesky of the lower triangle of S (m x m, m a multiple of 16) into L and inv(L) into Li (both
- * lower; the strict upper triangles of L and Li must be zero on entry).  S is overwritten. */
+/* Cholesky of the lower triangle of S (m x m, m a multiple of 16) into L, and into Li the inverses of L's
+ * diagonal blocks of 4096 rows (all of inv(L) when m <= 4096); both lower, their strict upper triangles must be
+ * zero on entry.  S is overwritten.  slamk_stage_gain_dev takes the pair (L, Li). */
 int slamk_cholesky_inverse_dev(double* S_dev, double* L_dev, double* Li_dev, int m, int ld, void* stream);
 
 /* ---- introspection for tests and benchmarks (no counterpart in the reference) ----------- */

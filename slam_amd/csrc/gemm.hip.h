@@ -67,7 +67,16 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmArgs g)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // Tile of this workgroup.  With a trimmed k range the tiles differ in length by up to the tile count: the
+    // workgroups are dealt in dispatch order (x fastest) to the tiles longest first, so that the short ones fill
+    // the tail of the launch.
+    int tm = blockIdx.y, tn = blockIdx.x;
+    if (TRI != TRI_NONE) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x, nx = gridDim.x, ny = gridDim.y;
+        if (TRI == TRI_A_KLE_M) { tm = ny - 1 - lin / nx; tn = lin % nx; }
+        else { tn = lin / ny; tm = lin % ny; if (TRI == TRI_B_KLE_N) tn = nx - 1 - tn; }
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
     if (LOWER && n0 > m0 + BM - 1) return;          // tile lies strictly above the diagonal
 
     const int b1 = blockIdx.z / g.nb2, b2 = blockIdx.z - b1 * g.nb2;

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -343,7 +344,12 @@ int run_predict(slamk_handle* h, const Range& rg, const double* qbw, const doubl
     ProfScope ps(h, PC_STRUCT_PREDICT, st);
     // P <- F P F^T + Q      (calcP, src/slam/main.cpp:526-530, G = I)
     const int nt = (nl + 2) / 3;
-    hipLaunchKernelGGL(predict_cov_kernel, dim3((nt * nt + 255) / 256, B), dim3(256), 0, st, rg.fv, rg.fv.P, rg.T, nl);
+    if (nt <= 128) {           // moderate sizes: bands of row triples staged through LDS, all global accesses contiguous
+        const int nthr = 256, hband = nthr / nt;     // 128 and 512 threads measured slower (0.32, 0.30 vs 0.28 ms)
+        hipLaunchKernelGGL(predict_cov_band_kernel, dim3((nt + hband - 1) / hband, B), dim3(nthr),
+                           predict_band_lds_bytes(nl, hband), st, rg.fv, rg.fv.P, rg.T, nl, hband);
+    } else
+        hipLaunchKernelGGL(predict_cov_kernel, dim3((nt * nt + 255) / 256, B), dim3(256), 0, st, rg.fv, rg.fv.P, rg.T, nl);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -354,6 +360,33 @@ Range after_predict(const Range& rg)
     Range r = rg;
     std::swap(r.fv.P, r.T);
     return r;
+}
+
+constexpr int CHOL_NB = 128;       // diagonal block of the blocked Cholesky (one workgroup factors and inverts it)
+// inv(L) is formed for the diagonal blocks of this many rows (a power of two times CHOL_NB); SLAMK_INV_BS overrides
+// the default for tuning and for exercising the multi-block solves on small matrices.
+int inv_block_rows()
+{
+    static const int bs = [] {
+        const char* e = getenv("SLAMK_INV_BS");
+        const int want = e ? atoi(e) : 4096;
+        int v = CHOL_NB;
+        while (v * 2 <= want) v *= 2;
+        return v;
+    }();
+    return bs;
+}
+#define INV_BS inv_block_rows()
+// Outer panel width of the two-level factorisation (a multiple of CHOL_NB); SLAMK_CHOL_OB overrides it for tuning.
+int chol_outer_block()
+{
+    static const int ob = [] {
+        const char* e = getenv("SLAMK_CHOL_OB");
+        int v = e ? atoi(e) : 512;
+        if (v < CHOL_NB) v = CHOL_NB;
+        return v / CHOL_NB * CHOL_NB;
+    }();
+    return ob;
 }
 
 template <int MT>
@@ -383,37 +416,56 @@ int launch_chol_inv_block(slamk_handle* h, double* Sp, double* Lp, double* Lip, 
     }
 }
 
-// S (lower) -> L (Cholesky factor) and Li = inv(L); S is used as scratch afterwards.
+// S (lower) -> L (Cholesky factor) and Li = the inverses of L's diagonal blocks of INV_BS rows (all of inv(L) when
+// ml <= INV_BS); S is used as scratch afterwards.
 int cholesky_inverse(slamk_handle* h, double* Sp, double* Lp, double* Lip, int ldm, long long sM, int B, int ml,
                      int* status, hipStream_t st)
 {
-    const int NB = 128;
-    // blocked right-looking Cholesky of S (lower) into L, diagonal-block inverses into Li
-    for (int j0 = 0; j0 < ml; j0 += NB) {
-        const int nb = std::min(NB, ml - j0);
-        {
-            ProfScope ps(h, PC_POTF2, st);
-            int rc = launch_chol_inv_block(h, Sp, Lp, Lip, ldm, sM, B, j0, nb, status, st);
-            if (rc) return rc;
+    const int NB = CHOL_NB, OB = chol_outer_block();
+    // Blocked right-looking Cholesky of S (lower) into L, diagonal-block inverses into Li, on two levels: inside
+    // an outer panel of OB columns the trailing update after every diagonal block only reaches the panel's own
+    // columns (rank NB); the columns right of the panel take one rank-OB update when the panel is complete, which
+    // reads and writes the large trailing matrix OB / NB times less often.
+    for (int J0 = 0; J0 < ml; J0 += OB) {
+        const int J1 = std::min(ml, J0 + OB);
+        for (int j0 = J0; j0 < J1; j0 += NB) {
+            const int nb = std::min(NB, ml - j0);
+            {
+                ProfScope ps(h, PC_POTF2, st);
+                int rc = launch_chol_inv_block(h, Sp, Lp, Lip, ldm, sM, B, j0, nb, status, st);
+                if (rc) return rc;
+            }
+            const int rem = ml - j0 - nb;
+            if (rem <= 0) break;
+            ProfScope ps(h, PC_GEMM_CHOL, st);
+            const long long o21 = (long long)(j0 + nb) * ldm + j0, o11 = (long long)j0 * ldm + j0;
+            const long long o22 = (long long)(j0 + nb) * ldm + (j0 + nb);
+            // L21 = S21 inv(L11)^T
+            HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_B_KLE_N>(
+                          gargs(Sp + o21, ldm, sM, Lip + o11, ldm, sM, Lp + o21, ldm, sM, rem, nb, nb), B, st)));
+            // S22 -= L21 L21^T, lower tiles, columns of this outer panel only
+            const int nin = J1 - (j0 + nb);
+            if (nin > 0)
+                HIPCHK(h, (launch_gemm<true, EPI_NONE, true, TRI_NONE>(
+                              gargs(Lp + o21, ldm, sM, Lp + o21, ldm, sM, Sp + o22, ldm, sM, rem, nin, nb, -1.0, 1.0),
+                              B, st)));
         }
-        const int rem = ml - j0 - nb;
-        if (rem <= 0) break;
-        ProfScope ps(h, PC_GEMM_CHOL, st);
-        const long long o21 = (long long)(j0 + nb) * ldm + j0, o11 = (long long)j0 * ldm + j0;
-        const long long o22 = (long long)(j0 + nb) * ldm + (j0 + nb);
-        // L21 = S21 inv(L11)^T
-        HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_B_KLE_N>(
-                      gargs(Sp + o21, ldm, sM, Lip + o11, ldm, sM, Lp + o21, ldm, sM, rem, nb, nb), B, st)));
-        // S22 -= L21 L21^T (lower tiles only)
-        HIPCHK(h, (launch_gemm<true, EPI_NONE, true, TRI_NONE>(
-                      gargs(Lp + o21, ldm, sM, Lp + o21, ldm, sM, Sp + o22, ldm, sM, rem, rem, nb, -1.0, 1.0),
-                      B, st)));
+        const int remo = ml - J1;
+        if (remo > 0) {          // the rest of the trailing matrix: one update of rank J1 - J0
+            ProfScope ps(h, PC_GEMM_CHOL, st);
+            const long long oL = (long long)J1 * ldm + J0, oS = (long long)J1 * ldm + J1;
+            HIPCHK(h, (launch_gemm<true, EPI_NONE, true, TRI_NONE>(
+                          gargs(Lp + oL, ldm, sM, Lp + oL, ldm, sM, Sp + oS, ldm, sM, remo, remo, J1 - J0, -1.0, 1.0),
+                          B, st)));
+        }
     }
     // inv(L) by recursive doubling on the block diagonal:
     //   inv([[A,0],[Bk,C]]) = [[inv A, 0], [-inv C * Bk * inv A, inv C]]
     // S's lower part is dead after the factorisation and holds the intermediate Bk * inv A.
+    // The doubling stops at blocks of INV_BS rows: gain_from_factor runs the two triangular solves block-wise with
+    // these diagonal-block inverses, so the levels above (most of the cost of a full inverse) are never built.
     ProfScope ps_inv(h, PC_GEMM_CHOL, st);
-    for (int s = NB; s < ml; s *= 2) {
+    for (int s = NB; s < std::min(ml, INV_BS); s *= 2) {
         const int nfull = ml / (2 * s), r = ml - nfull * 2 * s;
         for (int pass = 0; pass < 2; ++pass) {
             int cnt, M, base;
@@ -431,6 +483,39 @@ int cholesky_inverse(slamk_handle* h, double* Sp, double* Lp, double* Lip, int l
             g2.sA2 = g2.sB2 = g2.sC2 = s2; g2.nb2 = cnt;
             HIPCHK(h, (launch_gemm<false, EPI_NONE, false, TRI_A_KLE_M>(g2, B * cnt, st)));
         }
+    }
+    return 0;
+}
+
+// K = W S^-1 = (W L^-T) L^-1 and K R from the factor L and the inverses Li of its diagonal INV_BS-blocks, as two
+// block triangular solves (calcK, src/slam/main.cpp:547-550 solved by Cholesky instead of LU):
+//     Y_j = (W_j - sum_{k<j} Y_k L_jk^T) inv(L_jj)^T,  j ascending;   K_j = (Y_j - sum_{k>j} K_k L_kj) inv(L_jj),  j descending.
+// W (rows x ml) is overwritten; every product is a GEMM with at least min(ml, INV_BS) columns.
+int gain_from_factor(slamk_handle* h, double* W, double* Y, double* K, double* KR, int ldw, long long sW,
+                     const double* L, const double* Li, int ldl, long long sL, const double* rdiag, long long sR,
+                     int rows, int ml, int B, hipStream_t st)
+{
+    const int nbk = (ml + INV_BS - 1) / INV_BS;
+    for (int j = 0; j < nbk; ++j) {
+        const int c0 = j * INV_BS, wj = std::min(INV_BS, ml - c0);
+        const long long odiag = (long long)c0 * ldl + c0;
+        if (j > 0)
+            HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_NONE>(
+                          gargs(Y, ldw, sW, L + (long long)c0 * ldl, ldl, sL, W + c0, ldw, sW, rows, wj, c0, -1.0, 1.0), B, st)));
+        HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_B_KLE_N>(
+                      gargs(W + c0, ldw, sW, Li + odiag, ldl, sL, Y + c0, ldw, sW, rows, wj, wj), B, st)));
+    }
+    for (int j = nbk - 1; j >= 0; --j) {
+        const int c0 = j * INV_BS, wj = std::min(INV_BS, ml - c0), c1 = c0 + wj;
+        const long long odiag = (long long)c0 * ldl + c0;
+        if (c1 < ml)
+            HIPCHK(h, (launch_gemm<false, EPI_NONE, false, TRI_NONE>(
+                          gargs(K + c1, ldw, sW, L + (long long)c1 * ldl + c0, ldl, sL, Y + c0, ldw, sW, rows, wj, ml - c1, -1.0,
+                                1.0), B, st)));
+        // K_j and K_j R (R diagonal) from the same accumulators
+        GemmArgs g = gargs(Y + c0, ldw, sW, Li + odiag, ldl, sL, K + c0, ldw, sW, rows, wj, wj, 1.0, 0.0, rdiag + c0, sR);
+        g.C2 = KR + c0;
+        HIPCHK(h, (launch_gemm<false, EPI_DUAL_COLSCALE, false, TRI_B_KGE_N>(g, B, st)));
     }
     return 0;
 }
@@ -538,13 +623,8 @@ int run_update(slamk_handle* h, const Range& rg, const double* qbw, const double
         int rc = run_cholesky_inverse(h, rg, ml, st);
         if (rc) return rc;
         ProfScope ps(h, PC_GEMM_GAIN, st);
-        // K = W S^-1 = (W Li^T) Li                   (:547-550 solved by Cholesky instead of LU)
-        HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_B_KLE_N>(
-                      gargs(rg.W, ldm, sNM, rg.Li, ldm, sM, rg.Y, ldm, sNM, nl, ml, ml), B, st)));
-        // K and, for the Joseph form, K R (R diagonal) from the same accumulators
-        GemmArgs g = gargs(rg.Y, ldm, sNM, rg.Li, ldm, sM, rg.K, ldm, sNM, nl, ml, ml, 1.0, 0.0, rg.fv.rdiag, ldm);
-        g.C2 = rg.KR;
-        HIPCHK(h, (launch_gemm<false, EPI_DUAL_COLSCALE, false, TRI_B_KGE_N>(g, B, st)));
+        rc = gain_from_factor(h, rg.W, rg.Y, rg.K, rg.KR, ldm, sNM, rg.L, rg.Li, ldm, sM, rg.fv.rdiag, ldm, nl, ml, B, st);
+        if (rc) return rc;
     }
     if (use_fused_joseph(nl, ml)) {
         // small filters: A = I - K H, A P and the Joseph (or simple) form in one workgroup per filter
@@ -1235,20 +1315,19 @@ int slamk_stage_eye_minus_kh_dev(slamk_handle* h, const double* K_dev, int ldk, 
     return SLAMK_OK;
 }
 
-// Y = W Li^T, K = Y Li and K R = K diag(r) for `rows` rows of W (m x m lower-triangular Li, m a multiple of 16).
-int slamk_stage_gain_dev(slamk_handle* h, const double* W_dev, int rows, int m, int ld, const double* Li_dev, int ldli,
-                         double* Y_dev, double* K_dev, double* KR_dev, const double* r_dev, void* stream)
+// K = W S^-1 and K R = K diag(r) for `rows` rows of W from the outputs L, Li of slamk_cholesky_inverse_dev
+// (m x m, m a multiple of 16).  W is overwritten, Y is workspace.
+int slamk_stage_gain_dev(slamk_handle* h, double* W_dev, int rows, int m, int ld, const double* L_dev, const double* Li_dev,
+                         int ldli, double* Y_dev, double* K_dev, double* KR_dev, const double* r_dev, void* stream)
 {
-    if (!h || !W_dev || !Li_dev || !Y_dev || !K_dev || !KR_dev || !r_dev || rows < 16 || (rows & 15) || m < 16 || (m & 15))
+    if (!h || !W_dev || !L_dev || !Li_dev || !Y_dev || !K_dev || !KR_dev || !r_dev || rows < 16 || (rows & 15) || m < 16 ||
+        (m & 15))
         return SLAMK_EINVAL;
     if (ld < m || ldli < m) return fail(h, SLAMK_EINVAL, "stage_gain: leading dimensions too small");
     HIPCHK(h, hipSetDevice(h->device));
-    hipStream_t st = (hipStream_t)stream;
-    HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_B_KLE_N>(gargs(W_dev, ld, 0, Li_dev, ldli, 0, Y_dev, ld, 0, rows, m, m), 1, st)));
-    GemmArgs g = gargs(Y_dev, ld, 0, Li_dev, ldli, 0, K_dev, ld, 0, rows, m, m, 1.0, 0.0, r_dev, 0);
-    g.C2 = KR_dev;
-    HIPCHK(h, (launch_gemm<false, EPI_DUAL_COLSCALE, false, TRI_B_KGE_N>(g, 1, st)));
-    return SLAMK_OK;
+    int rc = gain_from_factor(h, W_dev, Y_dev, K_dev, KR_dev, ld, 0, L_dev, Li_dev, ldli, 0, r_dev, 0, rows, m, 1,
+                              (hipStream_t)stream);
+    return rc ? rc : SLAMK_OK;
 }
 
 int slamk_stage_apply_dev(slamk_handle* h, const double* K_dev, int ldk, int32_t* applied_dev, void* stream)
@@ -1439,20 +1518,29 @@ double slamk_flops_update_stage(int n, int m, int update_form, int stage)
         return tp * 8192.0;
     }
     if (stage == 0) {
-        const int NB = 128;
-        for (int j0 = 0; j0 < ml; j0 += NB) {
-            const int nb = std::min(NB, ml - j0), rem = ml - j0 - nb;
-            if (rem <= 0) break;
-            f += gemm_flops(rem, nb, nb, false, TRI_B_KLE_N);
-            f += gemm_flops(rem, rem, nb, true, TRI_NONE);
+        const int NB = CHOL_NB, OB = chol_outer_block();
+        for (int J0 = 0; J0 < ml; J0 += OB) {
+            const int J1 = std::min(ml, J0 + OB);
+            for (int j0 = J0; j0 < J1; j0 += NB) {
+                const int nb = std::min(NB, ml - j0), rem = ml - j0 - nb;
+                if (rem <= 0) break;
+                f += gemm_flops(rem, nb, nb, false, TRI_B_KLE_N);
+                if (J1 - (j0 + nb) > 0) f += gemm_flops(rem, J1 - (j0 + nb), nb, true, TRI_NONE);
+            }
+            if (ml - J1 > 0) f += gemm_flops(ml - J1, ml - J1, J1 - J0, true, TRI_NONE);
         }
-        for (int s = NB; s < ml; s *= 2) {
+        for (int s = NB; s < std::min(ml, INV_BS); s *= 2) {
             const int nfull = ml / (2 * s), r = ml - nfull * 2 * s;
             f += nfull * (gemm_flops(s, s, s, false, TRI_B_KGE_N) + gemm_flops(s, s, s, false, TRI_A_KLE_M));
             if (r > s) f += gemm_flops(r - s, s, s, false, TRI_B_KGE_N) + gemm_flops(r - s, s, r - s, false, TRI_A_KLE_M);
         }
-        f += gemm_flops(nl, ml, ml, false, TRI_B_KLE_N);           // Y
-        f += gemm_flops(nl, ml, ml, false, TRI_B_KGE_N);           // K
+        for (int c0 = 0; c0 < ml; c0 += INV_BS) {         // the two block triangular solves
+            const int wj = std::min(INV_BS, ml - c0), c1 = c0 + wj;
+            if (c0 > 0) f += gemm_flops(nl, wj, c0, false, TRI_NONE);
+            f += gemm_flops(nl, wj, wj, false, TRI_B_KLE_N);
+            if (c1 < ml) f += gemm_flops(nl, wj, ml - c1, false, TRI_NONE);
+            f += gemm_flops(nl, wj, wj, false, TRI_B_KGE_N);
+        }
         return f;
     }
     f += gemm_flops(nl, nl, nl, false, TRI_NONE);              // A P

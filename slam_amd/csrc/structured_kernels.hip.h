@@ -253,6 +253,119 @@ __global__ void __launch_bounds__(256) predict_cov_kernel(FilterView fv, const d
         }
 }
 
+// The same product for filters of moderate size, one workgroup per band of `hband` row triples (hband * nt <= blockDim.x):
+// the operand rows of the band (the velocity rows 3..5 and each triple's own group) and the compact rows of F go
+// through LDS with coalesced 16-byte loads, the finished band leaves through LDS the same way, so every global
+// access is a contiguous run; the arithmetic (and its order) is that of predict_cov_kernel.
+// grid (ceil(nt / hband), B), up to 512 threads; dynamic LDS predict_band_lds_bytes(nl, hband).
+__host__ __device__ inline size_t predict_band_lds_bytes(int nl, int hband)
+{
+    const int nt = (nl + 2) / 3;
+    return ((size_t)(hband + 1) * 3 * nl + 2 * 9 * (size_t)nt) * sizeof(double) + (size_t)nt * sizeof(int);
+}
+
+__global__ void __launch_bounds__(512) predict_cov_band_kernel(FilterView fv, const double* __restrict__ Pin,
+                                                                double* __restrict__ Pout, int nl, int hband)
+{
+    extern __shared__ double plds[];
+    const int b = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
+    const int nt = (nl + 2) / 3;
+    const int t0 = blockIdx.x * hband;
+    const int hb = min(hband, nt - t0);
+    const long long cb = (long long)b * fv.ldn;
+    const int ldn = fv.ldn;
+    const double* Pb = Pin + cb * ldn;
+    double* Ob = Pout + cb * ldn;
+    double* img = plds;                                   // [(hband + 1) * 3][nl]
+    double* cfa = img + (size_t)(hband + 1) * 3 * nl;     // [3 nt][3], zero past nl
+    double* cfg = cfa + 9 * nt;
+    int* cgs = reinterpret_cast<int*>(cfg + 9 * nt);      // [nt]
+
+    // stage: operand rows (16-byte pieces), compact rows of F, group starts
+    const int half = nl >> 1, pieces = (hb + 1) * 3 * half;
+    for (int idx = tid; idx < pieces; idx += nthr) {
+        const int row = idx / half, c2 = idx - row * half;
+        const int src = row < 3 ? 3 + row : fv.fgs[cb + 3 * (t0 + (row - 3) / 3)] + (row - 3) % 3;
+        reinterpret_cast<double2*>(img + (size_t)row * nl)[c2] =
+            reinterpret_cast<const double2*>(Pb + (long long)src * ldn)[c2];
+    }
+    for (int idx = tid; idx < 9 * nt; idx += nthr) {
+        const bool ok = idx < 3 * nl;
+        cfa[idx] = ok ? fv.fa[cb * 3 + idx] : 0.0;
+        cfg[idx] = ok ? fv.fg[cb * 3 + idx] : 0.0;
+    }
+    for (int idx = tid; idx < nt; idx += nthr) cgs[idx] = fv.fgs[cb + min(3 * idx, nl - 1)];
+    __syncthreads();
+
+    const int i = tid / nt, tl = tid - i * nt;
+    const bool live = i < hb;
+    const int tj = t0 + i;
+    const int j0 = 3 * tj, l0 = 3 * tl;
+    double acc[3][3];
+    if (live) {
+        const int gj = cgs[tj], gl = cgs[tl];
+        const bool jf = gj < 3, lf = gl < 3;
+        const int la = lf ? gl : 3, lb = lf ? 3 : gl;
+        const double* ra = cfa + 9 * tj;
+        const double* rg = cfg + 9 * tj;
+        const double* ca = cfa + 9 * tl;
+        const double* cg = cfg + 9 * tl;
+        double u[3][3], v[3][3];                           // column coefficients in ascending column order
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                u[c][k] = lf ? cg[3 * c + k] : ca[3 * c + k];
+                v[c][k] = lf ? ca[3 * c + k] : cg[3 * c + k];
+            }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bool own = (h == 0) == jf;               // this half of the sum runs over the triple's own group
+            const double* rows = own ? img + (size_t)(3 + 3 * i) * nl : img;
+            const double* fr = own ? rg : ra;
+#pragma unroll
+            for (int aa = 0; aa < 3; ++aa) {
+                const double* row = rows + (size_t)aa * nl;
+                const double p0 = row[la], p1 = row[la + 1], p2 = row[la + 2];
+                const double p3 = row[lb], p4 = row[lb + 1], p5 = row[lb + 2];
+                double t[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    double sacc = p0 * u[c][0];
+                    sacc = fma(p1, u[c][1], sacc); sacc = fma(p2, u[c][2], sacc);
+                    sacc = fma(p3, v[c][0], sacc); sacc = fma(p4, v[c][1], sacc); sacc = fma(p5, v[c][2], sacc);
+                    t[c] = sacc;
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const double f = fr[3 * r + aa];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) acc[r][c] = (h == 0 && aa == 0) ? f * t[c] : fma(f, t[c], acc[r][c]);
+                }
+            }
+        }
+        if (tj == tl)
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                if (j0 + r < nl) acc[r][r] += fv.qdiag[cb + j0 + r];
+    }
+    __syncthreads();
+    // the band leaves through the image: rows 3 i + r, then contiguous 16-byte stores
+    if (live)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (l0 + c < nl) img[(size_t)(3 * i + r) * nl + l0 + c] = acc[r][c];
+    __syncthreads();
+    const int orows = min(3 * hb, nl - 3 * t0);
+    for (int idx = tid; idx < orows * half; idx += nthr) {
+        const int row = idx / half, c2 = idx - row * half;
+        reinterpret_cast<double2*>(Ob + (long long)(3 * t0 + row) * ldn)[c2] =
+            reinterpret_cast<const double2*>(img + (size_t)row * nl)[c2];
+    }
+}
+
 // A = I - K H (updateP, src/slam/main.cpp:563-565), columns 3 .. nl-1.  Column 6 + 3 i + c only meets the
 // measurement rows of feature i; the velocity, bias and padding columns meet none.  Lanes along the column.
 // grid (ceil(nl / 64), ceil(nl / (4 rpw)), B), 256 threads.

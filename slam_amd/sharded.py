@@ -9,8 +9,8 @@ block and the only traffic is one all-gather per dense contraction:
 
     predict:  T_r = P_r F^T                    -> all-gather T ->  P_r = F_r T + Q_r
     update :  W_r = P_r H^T                    -> all-gather W ->  S_q = H_q W + R_q   -> all-gather S
-              L L^T = S, Li = inv(L)           (replicated: the part that does not scale)
-              K_r = (W_r Li^T) Li              -> all-gather K
+              L L^T = S, Li = inverses of L's diagonal blocks   (replicated: the part that does not scale)
+              K_r = W_r L^-T L^-1              -> all-gather K
               A_r = I_r - K_r H                -> all-gather A, all-gather P
               P_r <- (A_r P) A^T + (K_r R) K^T (Joseph form, row block r; three dense GEMMs)
               dx = K e, gate, mean update      (replicated, every rank holds the full K)
@@ -96,11 +96,12 @@ class HipBackend:
         self.fb._chk(self.L.slamk_stage_eye_minus_kh_dev(self.fb.h, K.data_ptr(), K.stride(0), row0, K.shape[0],
                                                          A.data_ptr(), A.stride(0), self.sptr))
 
-    def gain(self, Y, K, KR, W, Li, rd):
-        """Y = W Li^T, K = Y Li, KR = K diag(rd) for the rank's rows of W."""
+    def gain(self, Y, K, KR, W, Lm, Li, rd):
+        """K = W S^-1 (two block triangular solves with L and its diagonal-block inverses Li), KR = K diag(rd), for
+        the rank's rows of W; W is overwritten, Y is workspace."""
         m = Li.shape[0]
         assert W.stride(0) == Y.stride(0) == K.stride(0) == KR.stride(0) and rd.shape[0] >= m
-        self.fb._chk(self.L.slamk_stage_gain_dev(self.fb.h, W.data_ptr(), W.shape[0], m, W.stride(0), Li.data_ptr(),
+        self.fb._chk(self.L.slamk_stage_gain_dev(self.fb.h, W.data_ptr(), W.shape[0], m, W.stride(0), Lm.data_ptr(), Li.data_ptr(),
                                                  Li.stride(0), Y.data_ptr(), K.data_ptr(), KR.data_ptr(),
                                                  rd.data_ptr(), self.sptr))
 
@@ -224,7 +225,7 @@ class ShardedLargeMapFilter:
         self.Lm.zero_()
         self.Li.zero_()
         be.cholesky_inverse(self.S2, self.Lm, self.Li)              # replicated
-        be.gain(self.Y, self.K[r], self.KR, self.W[r], self.Li, self.rfull)   # K_r = (W_r Li^T) Li, K_r R
+        be.gain(self.Y, self.K[r], self.KR, self.W[r], self.Lm, self.Li, self.rfull)   # K_r = W_r S^-1, K_r R
         self._all_gather(self.K, self.bn)
         be.eye_minus_kh(self.Ar, self.K[r], self.r0)                # A_r = I_r - K_r H
         self._all_gather(self.G2, self.bn, self.Ar)

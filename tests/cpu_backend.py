@@ -64,7 +64,7 @@ class OracleBackend:
             if row0 + j < n:
                 A[j, row0 + j] += 1.0
 
-    def gain(self, Y, K, KR, W, Li, rd):
+    def gain(self, Y, K, KR, W, Lm, Li, rd):
         Y.copy_(W @ Li.T)
         K.copy_(Y @ Li)
         KR.copy_(K * rd[None, :Li.shape[0]])
