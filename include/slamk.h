@@ -187,6 +187,11 @@ int slamk_buffer_dev(slamk_handle* h, int which, double** ptr, int* rows, int* c
  * zero on entry.  S is overwritten.  slamk_stage_gain_dev takes the pair (L, Li). */
 int slamk_cholesky_inverse_dev(double* S_dev, double* L_dev, double* Li_dev, int m, int ld, void* stream);
 
+/* Tuning of the large-matrix path, process-wide (0 = leave as is): the outer panel width of the two-level
+ * blocked Cholesky (multiple of 128, default 512) and the rows of the diagonal blocks of L that are inverted for
+ * the block triangular solves (128 times a power of two, default 4096).  No counterpart in the reference. */
+int slamk_set_block_sizes(int chol_outer_block_cols, int inverse_block_rows);
+
 /* ---- introspection for tests and benchmarks (no counterpart in the reference) ----------- */
 /* ----- batched forms of the stream pre-processing filters that feed the estimator (device pointers) ----- */
 /* src/euler2qbw/euler2qbw.cpp:37-46: n rows (phi, theta, psi) -> n scalar-last quaternions. */

@@ -64,6 +64,7 @@ SIGNATURES = {
     "slamk_pre_img2body_dev": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "slamk_pre_fir_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp]),
     "slamk_set_debug": (C.c_int, [C.c_void_p, C.c_int]),
+    "slamk_set_block_sizes": (C.c_int, [C.c_int, C.c_int]),
     "slamk_debug_get": (C.c_int, [_H, C.c_int, _vp, _vp, _vp, _vp]),
     "slamk_debug_get_F": (C.c_int, [_H, C.c_int, _vp]),
     "slamk_dgemm_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int, C.c_longlong,

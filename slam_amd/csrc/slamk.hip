@@ -363,32 +363,29 @@ Range after_predict(const Range& rg)
 }
 
 constexpr int CHOL_NB = 128;       // diagonal block of the blocked Cholesky (one workgroup factors and inverts it)
-// inv(L) is formed for the diagonal blocks of this many rows (a power of two times CHOL_NB); SLAMK_INV_BS overrides
-// the default for tuning and for exercising the multi-block solves on small matrices.
-int inv_block_rows()
+// Block sizes of the large-matrix path, process-wide (slamk_set_block_sizes; SLAMK_CHOL_OB / SLAMK_INV_BS give the
+// initial values):
+//   outer panel width of the two-level factorisation, a multiple of CHOL_NB;
+//   rows of the diagonal blocks of L whose inverses are formed, a power of two times CHOL_NB.
+int round_outer_block(int v) { return std::max(v, CHOL_NB) / CHOL_NB * CHOL_NB; }
+int round_inverse_block(int want)
 {
-    static const int bs = [] {
-        const char* e = getenv("SLAMK_INV_BS");
-        const int want = e ? atoi(e) : 4096;
-        int v = CHOL_NB;
-        while (v * 2 <= want) v *= 2;
-        return v;
-    }();
-    return bs;
+    int v = CHOL_NB;
+    while (v * 2 <= want) v *= 2;
+    return v;
 }
-#define INV_BS inv_block_rows()
-// Outer panel width of the two-level factorisation (a multiple of CHOL_NB); SLAMK_CHOL_OB overrides it for tuning.
-int chol_outer_block()
+int& chol_outer_block_ref()
 {
-    static const int ob = [] {
-        const char* e = getenv("SLAMK_CHOL_OB");
-        int v = e ? atoi(e) : 512;
-        if (v < CHOL_NB) v = CHOL_NB;
-        return v / CHOL_NB * CHOL_NB;
-    }();
+    static int ob = [] { const char* e = getenv("SLAMK_CHOL_OB"); return round_outer_block(e ? atoi(e) : 512); }();
     return ob;
 }
-
+int& inv_block_rows_ref()
+{
+    static int bs = [] { const char* e = getenv("SLAMK_INV_BS"); return round_inverse_block(e ? atoi(e) : 4096); }();
+    return bs;
+}
+int chol_outer_block() { return chol_outer_block_ref(); }
+#define INV_BS inv_block_rows_ref()
 template <int MT>
 int launch_chol_inv_block_t(slamk_handle* h, double* Sp, double* Lp, double* Lip, int ldm, long long sM, int B, int j0,
                             int* status, hipStream_t st)
@@ -1427,6 +1424,14 @@ int slamk_debug_get_F(slamk_handle* h, int b, double* F)
     const int n = 9 + 3 * h->hf[b].nf;
     const size_t ldn = h->ldn;
     HIPCHK(h, hipMemcpy2D(F, n * 8, h->Fm + b * ldn * ldn, ldn * 8, n * 8, n, hipMemcpyDeviceToHost));
+    return SLAMK_OK;
+}
+
+int slamk_set_block_sizes(int chol_outer_block_cols, int inverse_block_rows)
+{
+    if (chol_outer_block_cols < 0 || inverse_block_rows < 0) return SLAMK_EINVAL;
+    if (chol_outer_block_cols) chol_outer_block_ref() = round_outer_block(chol_outer_block_cols);
+    if (inverse_block_rows) inv_block_rows_ref() = round_inverse_block(inverse_block_rows);
     return SLAMK_OK;
 }
 

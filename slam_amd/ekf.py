@@ -217,6 +217,13 @@ def flops_update_stage(n, m, update_form=0, stage=0):
     return _lib.lib().slamk_flops_update_stage(int(n), int(m), int(update_form), int(stage))
 
 
+def set_block_sizes(chol_outer_block=0, inverse_block=0):
+    """Process-wide block sizes of the large-matrix path (0 = keep): see slamk_set_block_sizes."""
+    rc = _lib.lib().slamk_set_block_sizes(int(chol_outer_block), int(inverse_block))
+    if rc:
+        raise SlamkError(rc, "set_block_sizes: negative size")
+
+
 def mfma_f64_probe(iters=20000):
     t = C.c_double(0)
     rc = _lib.lib().slamk_mfma_f64_probe(int(iters), C.byref(t))

@@ -423,6 +423,21 @@ def test_large_map_against_oracle():
     compare_snaps(so, sg)
 
 
+def test_large_map_with_small_blocks_runs_the_multi_block_solves():
+    """The same filter with 256-column outer panels and 256-row inverse blocks: several outer panels in the
+    factorisation and five block steps in each triangular solve, the code path of maps with m > 4096."""
+    nf = 220
+    st = synth.gen_stream(seed=2, nf=nf, steps=4, churn=False)
+    so, _ = helpers.run_oracle(st)
+    ekf.set_block_sizes(256, 256)
+    try:
+        fb = ekf.FilterBatch(max_features=nf, batch=1)
+        sg = helpers.run_gpu(st, fb)
+    finally:
+        ekf.set_block_sizes(512, 4096)
+    compare_snaps(so, sg)
+
+
 def test_full_size_batch_properties():
     """4096 filters x 32 features (the benchmark shape): a sample of filters against the oracle and
     symmetry / finiteness / positive diagonal of every covariance."""
