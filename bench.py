@@ -207,12 +207,17 @@ def large_map(torch, dev, nf=2000, iters=2):
     prof = fb.profile_read()
     gemm_ms = sum(prof[k][0] for k in prof if k.startswith("gemm")) / iters
     flops = ekf.flops_update(n, m, 0)
+    cov_ms = prof["gemm_cov_update"][0] / iters            # A P, (A P) A^T, (K R) K^T
+    cov_flops = ekf.flops_update_stage(n, m, 0, 1)
     P = fb.get_cov(0)
     ok = bool(np.all(np.isfinite(P)) and np.abs(P - P.T).max() == 0 and np.all(np.diag(P) > 0))
     fb.close()
     return {"workload": "single filter, %d features (n=%d, m=%d)" % (nf, n, m), "updates_per_s": 1.0 / t,
             "ms_per_update": t * 1e3, "gemm_tflops": flops / (gemm_ms * 1e-3) / 1e12,
             "frac_of_fp64_matrix_peak": flops / (gemm_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
+            "covariance_update": {"ms": cov_ms, "tflops": cov_flops / (cov_ms * 1e-3) / 1e12,
+                                  "frac_of_fp64_matrix_peak": cov_flops / (cov_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
+                                  "what": "Joseph form as executed: A P, lower tiles of (A P) A^T + (K R) K^T; HIP events"},
             "stages_ms": {k: round(v[0] / iters, 3) for k, v in prof.items()}, "cov_sane": ok}
 
 
