@@ -26,8 +26,6 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 enum Epilogue {
     EPI_NONE = 0,
-    EPI_DIAG_ADD = 1,    // C[i][i] += D[i]              (P = F T + Q,  S = H W + R)
-    EPI_EYE_MINUS = 2,   // C = I - A*op(B)              (A = I - K H)
     EPI_DUAL_COLSCALE = 3  // C = acc and C2[i][j] = acc * D[j]   (K and K R with diagonal R in one pass)
 };
 
@@ -44,7 +42,7 @@ struct GemmArgs {
     const double* B;
     double* C;
     double* C2;           // second output of EPI_DUAL_COLSCALE (same ld and strides as C)
-    const double* D;      // diagonal / column-scale vector for the epilogue (may be null)
+    const double* D;      // column-scale vector of EPI_DUAL_COLSCALE (null otherwise)
     int M, N, K;
     int lda, ldb, ldc;
     long long sA1, sB1, sC1, sD1;   // batch level 1 (independent filters)
@@ -217,9 +215,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmArgs g)
                 if (row < g.M && col < g.N) {
                     double v = g.alpha * acc[i][j][r];
                     double* c = C + (long long)row * g.ldc + col;
-                    if (EPI == EPI_EYE_MINUS) v = (row == col ? 1.0 : 0.0) - v;
                     if (g.beta != 0.0) v += g.beta * (*c);
-                    if (EPI == EPI_DIAG_ADD && row == col) v += D[row];
                     *c = v;
                     if (EPI == EPI_DUAL_COLSCALE) C2[(long long)row * g.ldc + col] = v * D[col];
                 }

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
         const int half = lane >> 5, l32 = lane & 31;
         // lane = feature i: columns 6 + 3 i .. + 2 from its 4 or 6 measurement rows, and its share of the
         // position columns 0..2 (summed over the lanes; lane 0 also carries the altitude row 0)
-        for (int i0 = 0; i0 < nf; i0 += 32) {
+        for (int i0 = 0; i0 < max(nf, 1); i0 += 32) {      // at least once: the altitude row exists without features
             const int i = i0 + l32;
             const bool live = i < nf;
             const int row0 = live ? fv.rowoff[(long long)b * fv.F + i] : 0;

@@ -114,6 +114,17 @@ def test_map_growing_through_every_path_in_one_handle():
         print("30 -> %d features: worst rel err %.2e" % (nf_end, worst))
 
 
+def test_map_that_empties_and_refills():
+    """Every feature vanishes (altitude-only updates: n = 9, m = 1), later frames bring four new ones."""
+    st = synth.gen_stream(seed=5, nf=3, steps=30, churn=False, drop_at=9, drop_count=3, add_at=18, add_count=4)
+    so, _ = helpers.run_oracle(st)
+    fb = ekf.FilterBatch(max_features=6, batch=1)
+    sg = helpers.run_gpu(st, fb)
+    assert min(len(s["ids"]) for s in sg) == 0 and len(sg[-1]["ids"]) == 4
+    worst = compare_snaps(so, sg)
+    print("empty map: worst rel err %.2e" % worst)
+
+
 def test_per_function_parity():
     """F, H, innovation, Cholesky factor and gain of one step against the oracle's functions."""
     st = synth.gen_stream(seed=4, nf=14, steps=7, churn=False)
