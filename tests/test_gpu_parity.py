@@ -125,6 +125,39 @@ def test_map_that_empties_and_refills():
     print("empty map: worst rel err %.2e" % worst)
 
 
+def test_altimeter_input_without_the_override():
+    """use_alt_override = 0: the first measurement is the altimeter value of the step (the reference overwrites it
+    with -1.34, src/slam/main.cpp:177-178; the switch exists so that callers with a live altimeter can use it)."""
+    st = synth.gen_stream(seed=41, nf=9, steps=25, churn=False)
+    inp = helpers.stream_inputs(st, 7)
+    po = orc.default_params()
+    po.use_alt_override = 0
+    f = orc.Filter(po)
+    f.X = st.init_pos
+    f.update_features(inp[0][5], inp[0][1])
+    f.old_pos[:] = f.X
+    pg = ekf.default_params()
+    pg.use_alt_override = 0
+    fb = ekf.FilterBatch(max_features=9, batch=1, params=pg)
+    fb.set_state(0, X=st.init_pos)
+    fb.frame(0, inp[0][5], inp[0][1])
+    rng = np.random.default_rng(3)
+    updates = 0
+    for k in range(1, len(inp)):
+        u, quat, ang, acc, dt, matches = inp[k]
+        alt = -1.3 + 0.05 * rng.standard_normal()
+        rc, _, applied = f.step(u | orc.ALT, orc.make_sensors(quat=quat, acc=acc, ang=ang, alt=alt), dt, matches)
+        assert rc == 0
+        if u & orc.IMG:
+            fb.frame(0, matches, quat)
+        fb.predict(quat, ang, acc, [dt])
+        if u & orc.IMG:
+            assert int(fb.update(quat, alt=[alt])[0]) == applied
+            updates += 1
+        assert helpers.rel_err(fb.get_state(0)[0], f.X) < TOL and helpers.rel_err(fb.get_cov(0), f.P) < TOL
+    assert updates >= 5
+
+
 def test_per_function_parity():
     """F, H, innovation, Cholesky factor and gain of one step against the oracle's functions."""
     st = synth.gen_stream(seed=4, nf=14, steps=7, churn=False)
@@ -337,6 +370,7 @@ def test_graph_mode_replays_the_same_iteration():
 def test_mixed_feature_counts_in_one_batch():
     """Filters with different nf share one launch (dimensions are padded to the batch maximum)."""
     sts = [synth.gen_stream(seed=30 + i, nf=nf, steps=7, churn=False) for i, nf in enumerate((4, 11, 7))]
+    sts.append(synth.gen_stream(seed=34, nf=3, steps=7, churn=False, drop_at=3, drop_count=3))   # empties at the 2nd frame
     B = len(sts)
     fb = ekf.FilterBatch(max_features=11, batch=B)
     inps = [helpers.stream_inputs(st, 5) for st in sts]
