@@ -86,10 +86,12 @@ def test_single_filter_stream_parity(nf, form):
     print("nf=%d form=%d worst rel err %.2e" % (nf, form, worst))
 
 
-@pytest.mark.parametrize("nf,ref_fraction,form", [(2, 0.5, 0), (38, 0.0, 0), (38, 0.0, 1), (26, 1.0, 0), (36, 1.0, 0)])
+@pytest.mark.parametrize("nf,ref_fraction,form", [(2, 0.5, 0), (38, 0.0, 0), (38, 0.0, 1), (26, 1.0, 0), (36, 1.0, 0),
+                                                  (13, 0.5, 0), (29, 0.5, 0), (1, 1.0, 0)])
 def test_fused_path_tile_count_edges(nf, ref_fraction, form):
     """Smallest filter, eight 16-row blocks of the state (n = 123), all-reflection rows (m = 157), and a filter
-    whose S exceeds the fused solver (m = 217) while its P still fits the fused covariance update (n = 117)."""
+    whose S exceeds the fused solver (m = 217) while its P still fits the fused covariance update (n = 117); state
+    dimensions that fill their tiles exactly (n = 48, 96: no padding rows); a single reflective feature."""
     st = synth.gen_stream(seed=70 + nf, nf=nf, steps=31, churn=False, ref_fraction=ref_fraction)
     so, _ = helpers.run_oracle(st)
     p = ekf.default_params()
