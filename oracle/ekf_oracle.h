@@ -10,7 +10,9 @@
  * be built in this image (it needs OpenCV 2.4, which is absent).  The
  * per-feature Jacobian (orc_jacobian_h) is pinned against values obtained by
  * evaluating the reference's own expression text (tests/golden/jacobian_h.json);
- * orc_rotation is pinned against the reference's img2body / rotate fixtures.
+ * the motion Jacobian (orc_motion_jacobian) and the feature rates of
+ * orc_dynamics_step likewise (tests/golden/motion_model.json); orc_rotation and
+ * orc_euler2quaternion against the reference's rotate / euler2qbw fixtures.
  * Everything else is "parity unpinned": it follows the reference source line
  * by line (citations below) but no reference-authored output exists to check
  * it against.  Dense products and the LU solve restate OpenCV 2.4 core

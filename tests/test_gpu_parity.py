@@ -226,6 +226,36 @@ def test_reference_jacobian_golden_through_the_kernel():
     assert worst < 1e-12, worst
 
 
+def test_reference_motion_model_golden_through_the_kernels():
+    """tests/golden/motion_model.json (values of the reference's closed-form motion Jacobian blocks and feature
+    rates) vs motion_rows_kernel / build_F_kernel and dynamics_kernel."""
+    from test_oracle_golden import motion_case
+    g = json.load(open(os.path.join(G, "motion_model.json")))
+    worst_f = worst_r = 0.0
+    for c in g["cases"]:
+        v, dt, feats, Fref = motion_case(c)
+        nf = len(feats)
+        fb = ekf.FilterBatch(max_features=nf, batch=1)
+        fb.set_debug(True)
+        pib = np.array([ft["pib"] for ft in feats])
+        fb.set_features(0, list(range(nf)), pib, np.zeros((nf, 3)), np.tile([0.0, 0, 0, 1], (nf, 1)), pib[:, :2],
+                        [0] * nf)
+        fb.set_state(0, X=np.zeros(3), V=v["V"])
+        fb.set_cov(0, np.eye(9 + 3 * nf))
+        fb.predict(v["qbw"], v["w"], [0.3, -0.2, 0.1], [dt])
+        F = fb.debug_get_F(0)
+        worst_f = max(worst_f, np.max(np.abs(F - Fref) / np.maximum(1.0, np.abs(Fref))))
+        want = pib + dt * np.array([ft["rate"] for ft in feats])
+        got = fb.get_features(0)["pib"]
+        worst_r = max(worst_r, np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))))
+        # P = F P F^T + Q with P = I: the propagated covariance is built from the same F
+        q0 = 256 * dt * dt
+        Q = np.diag([q0 * 0.1 * q0] * 3 + [q0] * (3 + 3 * nf) + [1e-5 * dt * dt] * 3)
+        assert helpers.rel_err(fb.get_cov(0), Fref @ Fref.T + Q) < 1e-13
+        fb.close()
+    assert worst_f < 1e-14 and worst_r < 1e-14, (worst_f, worst_r)
+
+
 def test_batch_of_independent_filters():
     """Filters of one batch see the same sensors but independent pixel noise; each must follow
     its own oracle run."""

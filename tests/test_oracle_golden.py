@@ -2,6 +2,8 @@
 
 * tests/golden/jacobian_h.json  -- values of the reference's own closed-form Jacobian text
   (src/slam/main.cpp:604-623), produced by oracle/gen_jacobian_golden.py.
+* tests/golden/motion_model.json -- values of the reference's closed-form motion Jacobian blocks and feature rates
+  (src/slam/main.cpp:253-264,290-299,314-317, src/ARC/states.cpp:253-256), produced by oracle/gen_motion_golden.py.
 * tests/golden/euler2qbw_*.txt  -- head of src/euler2qbw/{euler,Mquat}.txt (MATLAB answers).
 * tests/golden/rotate_acc*.txt  -- head of src/rotate/testing/{acc,acc.rot} (rotate -e 0 0 p).
 """
@@ -28,6 +30,55 @@ def test_jacobian_h_matches_reference_expression():
         # structural zeros spelled out at main.cpp:608,612-616
         assert np.all(Hb[:, 3:] == 0) and np.all(Hb[2:, :2] == 0)
     assert worst < 1e-12, worst
+
+
+def motion_case(c):
+    """Inputs of one fixture case and the motion Jacobian assembled from the reference's block values the way
+    jacobianMotionModel places them (src/slam/main.cpp:266,319,329-340)."""
+    v = {k: np.array([fh(x) for x in c[k]]) for k in ("qbw", "w", "V", "Fb1")}
+    dt = fh(c["dt"])
+    feats = [{k: np.array([fh(x) for x in f[k]]) for k in f} for f in c["features"]]
+    nf = len(feats)
+    n = 9 + 3 * nf
+    F = np.zeros((n, n))
+    F[0:6, 0:6] = v["Fb1"].reshape(6, 6)
+    for i, f in enumerate(feats):
+        F[6 + 3 * i:9 + 3 * i, 0:6] = f["Fib"].reshape(3, 6)
+        F[6 + 3 * i:9 + 3 * i, 6 + 3 * i:9 + 3 * i] = f["FiTemp"].reshape(3, 3)
+    F = dt * F + np.eye(n)
+    for r in range(3):
+        F[3 + r, 6 + 3 * nf + r] = -1 * dt
+    return v, dt, feats, F
+
+
+def oracle_filter_for(v, feats, quat):
+    f = orc.Filter()
+    f.update_features([(100 + i, 0.01 * i, 0.02, 0.0, 0.0) for i in range(len(feats))], quat)
+    f.V = v["V"]
+    for i, ft in enumerate(feats):
+        f.s.feat[i].pib[:] = list(ft["pib"])
+    return f
+
+
+def test_motion_jacobian_and_feature_rates_match_reference_expressions():
+    g = json.load(open(os.path.join(G, "motion_model.json")))
+    assert len(g["cases"]) == 48
+    worst_f = worst_r = 0.0
+    for c in g["cases"]:
+        v, dt, feats, Fref = motion_case(c)
+        f = oracle_filter_for(v, feats, v["qbw"])
+        acc = np.array([0.3, -0.2, 0.1])
+        s = orc.make_sensors(quat=v["qbw"], acc=acc, ang=v["w"])
+        F = f.motion_jacobian(s, dt)
+        worst_f = max(worst_f, np.max(np.abs(F - Fref) / np.maximum(1.0, np.abs(Fref))))
+        X0, pib0 = f.X, f.pib()
+        f.dynamics_step(s, dt)
+        want = pib0 + dt * np.array([ft["rate"] for ft in feats])
+        worst_r = max(worst_r, np.max(np.abs(f.pib() - want) / np.maximum(1.0, np.abs(want))))
+        # the rest of States::dynamics (states.cpp:229-233,244-246,260-262): X' = R(q) V, V' = acc - b
+        assert np.allclose(f.X, X0 + dt * (orc.rotation(v["qbw"]) @ v["V"]), rtol=0, atol=1e-15)
+        assert np.allclose(f.V, v["V"] + dt * acc, rtol=0, atol=1e-15)
+    assert worst_f < 1e-14 and worst_r < 1e-14, (worst_f, worst_r)
 
 
 def test_euler2quaternion_known_answers():
