@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmArgs g)
     const int wr = wave >> 1, wc = wave & 1;
     // Tile of this workgroup.  With a trimmed k range the tiles differ in length by up to the tile count: the
     // workgroups are dealt in dispatch order (x fastest) to the tiles longest first, so that the short ones fill
-    // the tail of the launch.
+    // the tail of the launch.  (Giving each XCD a contiguous eighth of the tile sequence, for L2 locality, measured
+    // no difference at 4096..10016: the kernel is not bound by L2 misses.)
     int tm = blockIdx.y, tn = blockIdx.x;
     if (TRI != TRI_NONE) {
         const int lin = blockIdx.y * gridDim.x + blockIdx.x, nx = gridDim.x, ny = gridDim.y;
