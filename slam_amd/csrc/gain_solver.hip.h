@@ -455,19 +455,17 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
 
     // ---- K^T_j = inv(L_jj)^T (Y^T_j - sum_{k>j} L_kj^T K^T_k),  j = MT-1 .. 0 -----------------------------
     if (!has_blk) return;
+    // Every finished tile of K leaves at once, through the wavefront's staging tile (128-byte runs per row): its
+    // stores drain while the products of the next tile run.
+    double* Kb = K + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li;
+    double* KRb = KR ? KR + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li : nullptr;
+    double mag = 0.0;                                    // a pivot that was not positive has made K NaN or infinite
 #pragma unroll
     for (int j = MT - 1; j >= 0; --j) {
         v4d acc = y[j];
 #pragma unroll
         for (int k = j + 1; k < MT; ++k) acc = tile_mma_regB<true, true>(lds + tile_index(k, j) * 256, y[k], acc, li, lk);
         y[j] = tile_mma_regB<true, false>(lds + tile_index(j, j) * 256, acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
-    }
-    // K tiles leave through the wavefront's staging tile: 128-byte runs per row
-    double* Kb = K + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li;
-    double* KRb = KR ? KR + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li : nullptr;
-    double mag = 0.0;                                    // a pivot that was not positive has made K NaN or infinite
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) stg[tsw(li, lk + 4 * r)] = y[j][r];
 #pragma unroll
