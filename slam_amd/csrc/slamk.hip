@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -139,6 +140,8 @@ struct ProfScope {
 int ensure_dynamic_lds(slamk_handle* h, const void* func, size_t bytes)
 {
     static std::vector<std::pair<const void*, int>> done;
+    static std::mutex mtx;                       // handles of several host threads share the table
+    std::lock_guard<std::mutex> lock(mtx);
     int dev = 0;
     HIPCHK(h, hipGetDevice(&dev));
     for (const auto& d : done)

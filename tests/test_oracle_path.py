@@ -123,3 +123,14 @@ def test_lu_gain_equals_cholesky_gain():
     A = np.eye(P.shape[0]) - Kc @ H
     joseph = A @ P @ A.T + Kc @ np.diag(rd) @ Kc.T
     assert helpers.rel_err(joseph, orc.update_p(P, K, H)) < 1e-11
+
+
+def test_bench_cpu_baseline_leg_runs_on_a_small_sample():
+    """bench.py's CPU leg (the oracle timed on a bounded sample of the batch) and its input builder, on the CPU."""
+    import torch
+    import bench
+    st, steps = bench.build_inputs(torch, torch.device("cpu"), 3, 5, 4, 0)
+    assert steps[0]["src"].shape == (3, 2, 5) and steps[0]["qbw"].shape == (3, 4)
+    r = bench.cpu_baseline(st, steps, 5, 1, 4, budget_s=0.05, max_filters=2)
+    assert r["kind"] == "port" and r["cores"] == 1 and r["unit"] == "EKF updates/s" and r["value"] > 0
+    assert "sample" in r
