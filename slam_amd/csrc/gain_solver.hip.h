@@ -371,8 +371,20 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
     double* crd = chb + 3 * M;                           // [M]
     int* ccs = reinterpret_cast<int*>(crd + M);          // [M]
     double* pan = scratch + SolverLds<MT>::COEF_TILES * 256;   // NT tiles: rows of W, 16 columns
+    // The first loads of P (columns 0..2 of every row, and the first panel's feature columns, whose start comes
+    // straight from global memory) are requested before the compact rows of H are staged: one global round trip
+    // instead of three in a row at the start of the workgroup.
+    const int ec = tid & 15, ea = tid >> 4;              // panel column, row within a group of 32 rows
+    double px[4][3], pf[4][3];                           // P[a][0..2] once, P[a][cs..cs+2] per panel
     {
         const long long rb = (long long)b * ldm;
+        const int cs0 = max(fv.hcs[rb + ec], 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double* row = Pb + (long long)min(ea + 32 * u, nl - 1) * ldn;
+            px[u][0] = row[0]; px[u][1] = row[1]; px[u][2] = row[2];
+            pf[u][0] = row[cs0]; pf[u][1] = row[cs0 + 1]; pf[u][2] = row[cs0 + 2];
+        }
         for (int t = tid; t < 3 * M; t += 512) { cha[t] = fv.ha[rb * 3 + t]; chb[t] = fv.hb[rb * 3 + t]; }
         for (int t = tid; t < M; t += 512) { crd[t] = rd[t]; ccs[t] = fv.hcs[rb + t]; }
     }
@@ -380,13 +392,6 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
     v4d y[MT];
     double* Kpark = K + (long long)b * sNM + (long long)(16 * blk) * ldm;
     auto build = [&](auto with_y) {
-        const int ec = tid & 15, ea = tid >> 4;          // panel column, row within a group of 32 rows
-        double px[4][3], pf[4][3];                       // P[a][0..2] once, P[a][cs..cs+2] per panel
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const double* row = Pb + (long long)min(ea + 32 * u, nl - 1) * ldn;
-            px[u][0] = row[0]; px[u][1] = row[1]; px[u][2] = row[2];
-        }
         auto load_panel = [&](int j) {                   // the entries of P in the observed feature's columns
             const int cs = max(ccs[16 * j + ec], 0);
 #pragma unroll
@@ -395,7 +400,6 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
                 pf[u][0] = row[0]; pf[u][1] = row[1]; pf[u][2] = row[2];
             }
         };
-        load_panel(0);
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
             {
@@ -414,21 +418,28 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
             }
             if (j + 1 < MT) load_panel(j + 1);           // in flight while this panel is consumed
             __syncthreads();
-            for (int i = j + wave; i < MT; i += 8) {     // S tiles (i, j), i >= j
+            for (int i = j + wave; i < MT; i += 8) {     // S tiles (i, j), i >= j; lane = row q of S, 4 columns each
                 double* tl = lds + tile_index(i, j) * 256;
-                const double x0 = pan[tsw(0, li)], x1 = pan[tsw(1, li)], x2 = pan[tsw(2, li)];
+                const int q = 16 * i + li;
+                const int cs = max(ccs[q], 0);
+                const double a0 = cha[3 * q], a1 = cha[3 * q + 1], a2 = cha[3 * q + 2];
+                const double b0 = chb[3 * q], b1 = chb[3 * q + 1], b2 = chb[3 * q + 2];
+                const double rq = crd[q];
+                const double* f0 = pan + (cs >> 4) * 256 + (cs & 15) * 16;
+                const double* f1 = pan + ((cs + 1) >> 4) * 256 + ((cs + 1) & 15) * 16;
+                const double* f2 = pan + ((cs + 2) >> 4) * 256 + ((cs + 2) & 15) * 16;
+                const int s0 = cs & 14, s1 = (cs + 1) & 14, s2 = (cs + 2) & 14;        // column XOR of tsw for those rows
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = lk + 4 * r, q = 16 * i + row;
-                    const int cs = max(ccs[q], 0);
-                    double v = cha[3 * q] * x0;
-                    v = fma(cha[3 * q + 1], x1, v);
-                    v = fma(cha[3 * q + 2], x2, v);
-                    v = fma(chb[3 * q], pan[(cs >> 4) * 256 + tsw(cs & 15, li)], v);
-                    v = fma(chb[3 * q + 1], pan[((cs + 1) >> 4) * 256 + tsw((cs + 1) & 15, li)], v);
-                    v = fma(chb[3 * q + 2], pan[((cs + 2) >> 4) * 256 + tsw((cs + 2) & 15, li)], v);
-                    if (q == 16 * j + li) v += crd[q];
-                    tl[tsw(row, li)] = v;
+                    const int c = lk + 4 * r;
+                    double v = a0 * pan[tsw(0, c)];
+                    v = fma(a1, pan[tsw(1, c)], v);
+                    v = fma(a2, pan[tsw(2, c)], v);
+                    v = fma(b0, f0[c ^ s0], v);
+                    v = fma(b1, f1[c ^ s1], v);
+                    v = fma(b2, f2[c ^ s2], v);
+                    if (q == 16 * j + c) v += rq;
+                    tl[tsw(li, c)] = v;
                 }
             }
             if (has_blk) {                               // tile (blk, j) of W, transposed: accumulator layout of W^T
