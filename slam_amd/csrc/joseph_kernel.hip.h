@@ -93,14 +93,24 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
 #pragma unroll
             for (int t = 0; t < 6; ++t) ef[t] = (live && (t < 4 || six)) ? ev[row0 + t] : 0.0;
             const int l0 = 6 + 3 * i;
+            // the gain entries of the next pass are requested before this pass is worked on
+            double kn[7];
+            auto fetch = [&](int pass) {
+                const double* kr = Kb + (long long)(pass * 16 + wave * 2 + half) * ldk;
+#pragma unroll
+                for (int t = 0; t < 6; ++t) kn[t] = (live && (t < 4 || six)) ? kr[row0 + t] : 0.0;
+                kn[6] = alt ? kr[0] : 0.0;
+            };
+            fetch(0);
 #pragma unroll
             for (int pass = 0; pass < NT; ++pass) {
                 const int j = pass * 16 + wave * 2 + half;
-                const double* kr = Kb + (long long)j * ldk;
+                if (pass > 0 && NT > 7) fetch(pass);
                 double k[6];
 #pragma unroll
-                for (int t = 0; t < 6; ++t) k[t] = (live && (t < 4 || six)) ? kr[row0 + t] : 0.0;
-                const double ka = alt ? kr[0] : 0.0;
+                for (int t = 0; t < 6; ++t) k[t] = kn[t];
+                const double ka = kn[6];
+                if (pass + 1 < NT && NT <= 7) fetch(pass + 1);      // (no registers to spare for it at NT = 8)
                 double x[3] = {ka * g0, ka * g1, ka * g2};
                 double de = ka * e0;                     // this lane's share of dx_j = sum_q K[j][q] e[q]   (main.cpp:228)
 #pragma unroll
@@ -229,15 +239,23 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
                 for (int r = 0; r < 4; ++r) pre[r] = ksrc[r * r4 + 16 * (c + 1)];
             }
             if (active) {
+                // all operand fragments of the chunk are requested before the first product: one LDS latency per
+                // chunk instead of one per k step
+                double ka[4][NT], rq[4];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int off = tsw(li, 4 * s + lk);
-                    const double k0 = kc[J * 256 + off];
-                    const double bq = k0 * rds[16 * c + 4 * s + lk];
-                    o[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(k0, bq, o[0], 0, 0, 0);
+                    rq[s] = rds[16 * c + 4 * s + lk];
 #pragma unroll
-                    for (int t = 1; t < NT; ++t)
-                        if (J + t < NT) o[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kc[(J + t) * 256 + off], bq, o[t], 0, 0, 0);
+                    for (int t = 0; t < NT; ++t)
+                        if (J + t < NT) ka[s][t] = kc[(J + t) * 256 + off];
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const double bq = ka[s][0] * rq[s];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        if (J + t < NT) o[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ka[s][t], bq, o[t], 0, 0, 0);
                 }
             }
             if (KBUF == 1) __syncthreads();      // with two buffers the next store goes to the other one
