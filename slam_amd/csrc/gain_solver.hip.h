@@ -123,30 +123,51 @@ __device__ __forceinline__ void inv4(const double* l, const double* id, double* 
 //     X_bc = -(sum_{c < k <= b} X_bk L_kc) inv(L_cc),
 // again one LDS round trip per block column.  No divergent branches: lanes that own nothing in a step
 // keep their values through selects.
+// Two adjacent columns (c0 even) of row r of a tile in one 16-byte LDS access: the XOR of the tile image only
+// touches bits 1..3 of the column, so columns c0 and c0 + 1 stay neighbours.
+__device__ __forceinline__ double2 tile_ld2(const double* t, int r, int c0)
+{
+    return *reinterpret_cast<const double2*>(t + r * 16 + (c0 ^ (r & 14)));
+}
+__device__ __forceinline__ void tile_st2(double* t, int r, int c0, double a, double b)
+{
+    *reinterpret_cast<double2*>(t + r * 16 + (c0 ^ (r & 14))) = make_double2(a, b);
+}
+// four adjacent columns c0 .. c0 + 3 (c0 a multiple of 4) of row r
+__device__ __forceinline__ void tile_ld4(const double* t, int r, int c0, double* v)
+{
+    const double2 a = tile_ld2(t, r, c0), b = tile_ld2(t, r, c0 + 2);
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+__device__ __forceinline__ void tile_st4(double* t, int r, int c0, const double* v)
+{
+    tile_st2(t, r, c0, v[0], v[1]);
+    tile_st2(t, r, c0 + 2, v[2], v[3]);
+}
+
 __device__ __forceinline__ void diag_tile_factor_invert(double* t, double* xs, double* __restrict__ Lg, int ldl, int lane)
 {
     const int r = lane & 15, cg = lane >> 4, b = r >> 2, i = r & 3;
     double cur[4], idall[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) cur[q] = t[tsw(r, 4 * cg + q)];
+    tile_ld4(t, r, 4 * cg, cur);
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-        if (kb > 0) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) t[tsw(r, 4 * cg + q)] = cur[q];
-        }
+        if (kb > 0) tile_st4(t, r, 4 * cg, cur);
         double d[10], l[10], id[4], ar[4], xr[4];
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-            for (int jj = 0; jj <= ii; ++jj) d[ii * (ii + 1) / 2 + jj] = t[tsw(4 * kb + ii, 4 * kb + jj)];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ar[q] = t[tsw(r, 4 * kb + q)];
+        {   // lower triangle of the 4 x 4 pivot block: rows 4 kb .. 4 kb + 3, one or two 16-byte reads each
+            double w[4];
+            d[0] = t[tsw(4 * kb, 4 * kb)];
+            const double2 r1 = tile_ld2(t, 4 * kb + 1, 4 * kb);
+            d[1] = r1.x; d[2] = r1.y;
+            tile_ld4(t, 4 * kb + 2, 4 * kb, w);
+            d[3] = w[0]; d[4] = w[1]; d[5] = w[2];
+            tile_ld4(t, 4 * kb + 3, 4 * kb, w);
+            d[6] = w[0]; d[7] = w[1]; d[8] = w[2]; d[9] = w[3];
+        }
+        tile_ld4(t, r, 4 * kb, ar);
         double ac[4][4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ac[p][q] = t[tsw(4 * cg + p, 4 * kb + q)];
+        for (int p = 0; p < 4; ++p) tile_ld4(t, 4 * cg + p, 4 * kb, ac[p]);
         chol4(d, l, id);
 #pragma unroll
         for (int q = 0; q < 4; ++q) idall[4 * kb + q] = id[q];
@@ -164,20 +185,24 @@ __device__ __forceinline__ void diag_tile_factor_invert(double* t, double* xs, d
     }
     // the factor, zero above the diagonal
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        cur[q] = (4 * cg + q <= r) ? cur[q] : 0.0;
-        t[tsw(r, 4 * cg + q)] = cur[q];
-    }
+    for (int q = 0; q < 4; ++q) cur[q] = (4 * cg + q <= r) ? cur[q] : 0.0;
+    tile_st4(t, r, 4 * cg, cur);
     if (Lg) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) Lg[(long long)r * ldl + 4 * cg + q] = cur[q];
     }
     // inverse of the diagonal block of this lane's column group
     double lc[10], idc[4], xc[10];
-#pragma unroll
-    for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-        for (int jj = 0; jj <= ii; ++jj) lc[ii * (ii + 1) / 2 + jj] = t[tsw(4 * cg + ii, 4 * cg + jj)];
+    {
+        double w[4];
+        lc[0] = t[tsw(4 * cg, 4 * cg)];
+        const double2 r1 = tile_ld2(t, 4 * cg + 1, 4 * cg);
+        lc[1] = r1.x; lc[2] = r1.y;
+        tile_ld4(t, 4 * cg + 2, 4 * cg, w);
+        lc[3] = w[0]; lc[4] = w[1]; lc[5] = w[2];
+        tile_ld4(t, 4 * cg + 3, 4 * cg, w);
+        lc[6] = w[0]; lc[7] = w[1]; lc[8] = w[2]; lc[9] = w[3];
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         idc[q] = cg == 0 ? idall[q] : (cg == 1 ? idall[4 + q] : (cg == 2 ? idall[8 + q] : idall[12 + q]));
@@ -189,17 +214,23 @@ __device__ __forceinline__ void diag_tile_factor_invert(double* t, double* xs, d
                        : i == 1 ? (q <= 1 ? xc[1 + q] : 0.0)
                        : i == 2 ? (q <= 2 ? xc[3 + q] : 0.0) : xc[6 + q];
         xrow[q] = (cg == b) ? v : 0.0;
-        xs[tsw(r, 4 * cg + q)] = xrow[q];
     }
+    tile_st4(xs, r, 4 * cg, xrow);
 #pragma unroll
     for (int k = 1; k < 4; ++k) {
         double v[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int a = 0; a < 4 * k; ++a) {
-            const int ap = (4 * cg + 4 + a) & 15;          // only lanes with b - cg == k keep the result
-            const double xv = xs[tsw(r, ap)];
+        for (int a4 = 0; a4 < k; ++a4) {
+            const int ab = (4 * cg + 4 + 4 * a4) & 15;     // only lanes with b - cg == k keep the result
+            double xv[4];
+            tile_ld4(xs, r, ab, xv);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = fma(xv, t[tsw(ap, 4 * cg + c)], v[c]);
+            for (int a = 0; a < 4; ++a) {
+                double tr[4];
+                tile_ld4(t, ab + a, 4 * cg, tr);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = fma(xv[a], tr[c], v[c]);
+            }
         }
         const bool act = (b - cg == k);
         double o[4];
@@ -208,13 +239,10 @@ __device__ __forceinline__ void diag_tile_factor_invert(double* t, double* xs, d
         o[2] = -fma(v[3], xc[8], v[2] * xc[5]);
         o[3] = -(v[3] * xc[9]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            xrow[q] = act ? o[q] : xrow[q];
-            xs[tsw(r, 4 * cg + q)] = xrow[q];
-        }
+        for (int q = 0; q < 4; ++q) xrow[q] = act ? o[q] : xrow[q];
+        tile_st4(xs, r, 4 * cg, xrow);
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) t[tsw(r, 4 * cg + q)] = xrow[q];
+    tile_st4(t, r, 4 * cg, xrow);
 }
 
 // Tile Cholesky of the MT x MT lower tiles in LDS (tile (i, j) at tile_index(i, j)) together with the forward
