@@ -453,22 +453,27 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
                 const double a0 = cha[3 * q], a1 = cha[3 * q + 1], a2 = cha[3 * q + 2];
                 const double b0 = chb[3 * q], b1 = chb[3 * q + 1], b2 = chb[3 * q + 2];
                 const double rq = crd[q];
-                const double* f0 = pan + (cs >> 4) * 256 + (cs & 15) * 16;
-                const double* f1 = pan + ((cs + 1) >> 4) * 256 + ((cs + 1) & 15) * 16;
-                const double* f2 = pan + ((cs + 2) >> 4) * 256 + ((cs + 2) & 15) * 16;
-                const int s0 = cs & 14, s1 = (cs + 1) & 14, s2 = (cs + 2) & 14;        // column XOR of tsw for those rows
+                // columns 4 lk .. 4 lk + 3: neighbours in the tile image, two 16-byte accesses per row
+                double x0[4], x1[4], x2[4], y0[4], y1[4], y2[4], v[4];
+                tile_ld4(pan, 0, 4 * lk, x0);
+                tile_ld4(pan, 1, 4 * lk, x1);
+                tile_ld4(pan, 2, 4 * lk, x2);
+                tile_ld4(pan + (cs >> 4) * 256, cs & 15, 4 * lk, y0);
+                tile_ld4(pan + ((cs + 1) >> 4) * 256, (cs + 1) & 15, 4 * lk, y1);
+                tile_ld4(pan + ((cs + 2) >> 4) * 256, (cs + 2) & 15, 4 * lk, y2);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int c = lk + 4 * r;
-                    double v = a0 * pan[tsw(0, c)];
-                    v = fma(a1, pan[tsw(1, c)], v);
-                    v = fma(a2, pan[tsw(2, c)], v);
-                    v = fma(b0, f0[c ^ s0], v);
-                    v = fma(b1, f1[c ^ s1], v);
-                    v = fma(b2, f2[c ^ s2], v);
-                    if (q == 16 * j + c) v += rq;
-                    tl[tsw(li, c)] = v;
+                    const int c = 4 * lk + r;
+                    double w = a0 * x0[r];
+                    w = fma(a1, x1[r], w);
+                    w = fma(a2, x2[r], w);
+                    w = fma(b0, y0[r], w);
+                    w = fma(b1, y1[r], w);
+                    w = fma(b2, y2[r], w);
+                    if (q == 16 * j + c) w += rq;
+                    v[r] = w;
                 }
+                tile_st4(tl, li, 4 * lk, v);
             }
             if (has_blk) {                               // tile (blk, j) of W, transposed: accumulator layout of W^T
                 if constexpr (decltype(with_y)::value) {
