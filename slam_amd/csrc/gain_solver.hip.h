@@ -48,18 +48,21 @@ __device__ __forceinline__ v4d tile_mma_regB(const double* __restrict__ ta, v4d 
     return c;
 }
 
-// D = (+/-) A * Bt^T + C with both operands LDS tiles read by rows (B[k][j] = tb[j][k]).
+// D = (+/-) A * Bt^T + C with both operands LDS tiles read by rows (B[k][j] = tb[j][k]).  Each MFMA sums over four
+// values of k, one per lane group lk; WHICH four is free as long as both operands agree, so lane group lk takes
+// k = 4 lk + s in step s: its four operand values are neighbours in the tile image and come with two 16-byte reads.
 template <bool NEG>
 __device__ __forceinline__ v4d tile_mma_ldsBt(const double* __restrict__ ta, const double* __restrict__ tb, v4d c,
                                               int li, int lk)
 {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        double a = ta[tsw(li, 4 * s + lk)];
-        const double b = tb[tsw(li, 4 * s + lk)];
-        if (NEG) a = -a;
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-    }
+    const int o0 = li * 16 + ((4 * lk) ^ (li & 14)), o1 = li * 16 + ((4 * lk + 2) ^ (li & 14));
+    const double2 a01 = *reinterpret_cast<const double2*>(ta + o0), a23 = *reinterpret_cast<const double2*>(ta + o1);
+    const double2 b01 = *reinterpret_cast<const double2*>(tb + o0), b23 = *reinterpret_cast<const double2*>(tb + o1);
+    const double sg = NEG ? -1.0 : 1.0;
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(sg * a01.x, b01.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(sg * a01.y, b01.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(sg * a23.x, b23.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(sg * a23.y, b23.y, c, 0, 0, 0);
     return c;
 }
 
