@@ -8,7 +8,8 @@
 //   phase A  A = I - K H into LDS, and dx = K e (src/slam/main.cpp:228) from the same reads of K.  H is sparse: column 6 + 3 i + c of K H only sums the 4 or 6 measurement
 //            rows of feature i (one lane per feature, rows of K read as contiguous runs), columns 0..2 sum
 //            all rows (lanes along the row of K), the rest of A is I.  Wavefront `blk` then takes its 16
-//            rows of A in MFMA operand layout (lane (li, lk) holds A[16 blk + li][4 s + lk]).
+//            rows of A in MFMA operand layout (lane (li, lk) holds A[16 blk + li][16 kt + 4 lk + s]: four neighbours
+//            of the tile image per k tile, so that the operand reads of phases 2 are 16 bytes wide).
 //   phase P  P tiles replace A in LDS.
 //   phase 1  AP(blk, :) = A(blk, :) P with A from registers and P tiles from LDS; the row block is then
 //            written over P(blk, :) (all wavefronts have finished reading P by then).
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
     double af[4 * NT];
     if (active) {
 #pragma unroll
-        for (int s = 0; s < 4 * NT; ++s) af[s] = lds[(blk * NT + (s >> 2)) * 256 + tsw(li, 4 * (s & 3) + lk)];
+        for (int kt = 0; kt < NT; ++kt) tile_ld4(lds + (blk * NT + kt) * 256, li, 4 * lk, af + 4 * kt);
     }
     __syncthreads();
 #if JOSEPH_STOP == 1
@@ -168,7 +169,7 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
         for (int J = 0; J < NT; ++J) acc[J] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int s = 0; s < 4 * NT; ++s) {
-            const double* col = lds + (s >> 2) * NT * 256 + tsw(4 * (s & 3) + lk, li);
+            const double* col = lds + (s >> 2) * NT * 256 + tsw(4 * lk + (s & 3), li);
 #pragma unroll
             for (int J = 0; J < NT; ++J) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], col[J * 256], acc[J], 0, 0, 0);
         }
@@ -206,11 +207,19 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
     for (int t = 0; t < NT; ++t) o[t] = (v4d){0.0, 0.0, 0.0, 0.0};
     if (active) {
 #pragma unroll
-        for (int s = 0; s < 4 * NT; ++s) {
-            const double* rowp = lds + (J * NT + (s >> 2)) * 256 + tsw(li, 4 * (s & 3) + lk);
+        for (int kt = 0; kt < NT; ++kt) {
+            const double* rowp = lds + (J * NT + kt) * 256 + li * 16;
+            const int c0 = (4 * lk) ^ (li & 14), c1 = (4 * lk + 2) ^ (li & 14);
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (J + t < NT) o[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[t * NT * 256], af[s], o[t], 0, 0, 0);
+            for (int h = 0; h < 2; ++h) {                 // two k steps per 16-byte read of every tile of the column
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (J + t < NT) {
+                        const double2 a2 = *reinterpret_cast<const double2*>(rowp + t * NT * 256 + (h ? c1 : c0));
+                        o[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, af[4 * kt + 2 * h], o[t], 0, 0, 0);
+                        o[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, af[4 * kt + 2 * h + 1], o[t], 0, 0, 0);
+                    }
+            }
         }
     }
 #if JOSEPH_STOP == 4
@@ -242,14 +251,18 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
                 // all operand fragments of the chunk are requested before the first product: one LDS latency per
                 // chunk instead of one per k step
                 double ka[4][NT], rq[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int off = tsw(li, 4 * s + lk);
-                    rq[s] = rds[16 * c + 4 * s + lk];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        if (J + t < NT) ka[s][t] = kc[(J + t) * 256 + off];
+                {
+                    const double2 r01 = *reinterpret_cast<const double2*>(rds + 16 * c + 4 * lk);
+                    const double2 r23 = *reinterpret_cast<const double2*>(rds + 16 * c + 4 * lk + 2);
+                    rq[0] = r01.x; rq[1] = r01.y; rq[2] = r23.x; rq[3] = r23.y;
                 }
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (J + t < NT) {
+                        double w[4];
+                        tile_ld4(kc + (J + t) * 256, li, 4 * lk, w);
+                        ka[0][t] = w[0]; ka[1][t] = w[1]; ka[2][t] = w[2]; ka[3][t] = w[3];
+                    }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const double bq = ka[s][0] * rq[s];
