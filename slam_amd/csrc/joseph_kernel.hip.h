@@ -278,17 +278,26 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
     { double z = 0; for (int t = 0; t < NT; ++t) z += o[t][0] + o[t][1] + o[t][2] + o[t][3]; if (form == 99) Pb[tid] = z; return; }
 #endif
     if (!active) return;
+    // Every tile goes out twice: as it is (rows of 128 bytes), and mirrored.  The mirror image is read back
+    // transposed from a tile of LDS (the AP tiles are dead by now; wavefront w uses tile w) so that its stores are
+    // rows of 128 bytes as well instead of 64 single doubles a leading dimension apart.
+    double* sc = lds + wave * 256;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if (J + t >= NT) break;
         const int I = J + t;
 #pragma unroll
+        for (int r = 0; r < 4; ++r) sc[tsw(lk + 4 * r, li)] = o[t][r];
+#pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * I + lk + 4 * r, col = 16 * J + li;
-            if (row >= col) {
-                Pb[(long long)row * ldn + col] = o[t][r];
-                Pb[(long long)col * ldn + row] = o[t][r];
-            }
+            if (row >= col) Pb[(long long)row * ldn + col] = o[t][r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = li, bq = lk + 4 * r;             // element (a, bq) of the tile -> out[16 J + bq][16 I + a]
+            const double v = sc[tsw(a, bq)];
+            if (16 * I + a > 16 * J + bq) Pb[(long long)(16 * J + bq) * ldn + 16 * I + a] = v;
         }
     }
 }
