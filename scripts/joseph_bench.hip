@@ -37,7 +37,7 @@ int main()
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        joseph_kernel<NT><<<B, 512, lds>>>(fv, Kd, ldm, (long long)ldn * ldm, ml, 0, dxd);
+        joseph_kernel<NT><<<B, 512, lds>>>(fv, Kd, ldm, (long long)ldn * ldm, ml, 0, dxd, 0, nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("%s: %.3f ms\n", VARIANT, ms);

@@ -142,12 +142,10 @@ __global__ void __launch_bounds__(256) build_F_kernel(FilterView fv, const doubl
 // mu += dynamics(mu) * dt  (States::dynamics + add, src/ARC/states.cpp:222-263, :69-86).
 // One workgroup per filter; all increments use the pre-step V.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) dynamics_kernel(FilterView fv, const double* __restrict__ qbw,
-                                                        const double* __restrict__ w,
-                                                        const double* __restrict__ acc,
-                                                        const double* __restrict__ dtv)
+__device__ __forceinline__ void dynamics_filter(const FilterView& fv, int b, const double* __restrict__ qbw,
+                                                const double* __restrict__ w, const double* __restrict__ acc,
+                                                const double* __restrict__ dtv)
 {
-    const int b = blockIdx.x;
     const int nf = fv.nf[b];
     const double dt = dtv[b];
     const double V0 = fv.V[3 * b], V1 = fv.V[3 * b + 1], V2 = fv.V[3 * b + 2];
@@ -174,11 +172,18 @@ __global__ void __launch_bounds__(256) dynamics_kernel(FilterView fv, const doub
     }
 }
 
+__global__ void __launch_bounds__(256) dynamics_kernel(FilterView fv, const double* __restrict__ qbw,
+                                                        const double* __restrict__ w,
+                                                        const double* __restrict__ acc,
+                                                        const double* __restrict__ dtv)
+{
+    dynamics_filter(fv, blockIdx.x, qbw, w, acc, dtv);
+}
+
 // old_pos = X and inverse-depth clamp (src/slam/main.cpp:168, src/ARC/states.cpp:91-103).
 // b_only >= 0 restricts the kernel to one filter.
-__global__ void __launch_bounds__(256) frame_begin_kernel(FilterView fv, int b_only)
+__device__ __forceinline__ void frame_begin_filter(const FilterView& fv, int b)
 {
-    const int b = b_only >= 0 ? b_only : blockIdx.x;
     const int nf = fv.nf[b];
     double* p2 = fv.pib + (long long)b * 3 * fv.F + 2 * fv.F;
     for (int i = threadIdx.x; i < nf; i += blockDim.x) {
@@ -188,6 +193,11 @@ __global__ void __launch_bounds__(256) frame_begin_kernel(FilterView fv, int b_o
         p2[i] = d;
     }
     if (threadIdx.x < 3) fv.old_pos[3 * b + threadIdx.x] = fv.X[3 * b + threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256) frame_begin_kernel(FilterView fv, int b_only)
+{
+    frame_begin_filter(fv, b_only >= 0 ? b_only : blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -32,7 +32,8 @@ namespace slamk {
 
 template <int NT>
 __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double* __restrict__ K, int ldk,
-                                                      long long sK, int ml, int form, double* __restrict__ dx)
+                                                      long long sK, int ml, int form, double* __restrict__ dx,
+                                                      int apply, int* __restrict__ applied)
 {
     extern __shared__ double lds[];                     // NT * NT tiles of 256 doubles (tile (I, J) at I * NT + J)
     constexpr int KBUF = (NT <= 7) ? 2 : 1;             // chunk buffers of K (LDS holds two up to NT = 7)
@@ -162,6 +163,27 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
     { double z = lds[tid]; if (active) for (int s = 0; s < 4 * NT; ++s) z += af[s]; if (form == 99) Pb[tid] = z; return; }
 #endif
 
+    // Gate on the velocity correction and mean update (src/slam/main.cpp:229-232), as gain_apply_kernel: the work of
+    // wavefront 4, which owns no row block up to NT = 7 and would otherwise wait at the next barrier through phase 1
+    // (its loads of V must not sit in front of a barrier the other wavefronts wait at).  Nothing else in this kernel
+    // reads X, V or the features.
+    if (apply && wave == 4) {
+        const double* V = fv.V + 3 * b;
+        const bool gate_ok = fabs(V[0] - dxs[3]) + fabs(V[1] - dxs[4]) + fabs(V[2] - dxs[5]) < fv.gate;
+        if (lane == 0 && applied) applied[b] = gate_ok;
+        if (gate_ok) {
+            const double dv = lane < 3 ? dxs[3 + lane] : 0.0;      // read by every lane before any lane writes V
+            if (lane < 3) {
+                fv.X[3 * b + lane] += dxs[lane];
+                fv.V[3 * b + lane] += dv;
+            }
+            const long long fb = (long long)b * 3 * fv.F;
+            for (int t = lane; t < 3 * nf; t += 64) {
+                const int i = t / 3, c = t - 3 * i;
+                fv.pib[fb + (long long)c * fv.F + i] += dxs[6 + t];
+            }
+        }
+    }
     // ---- phase 1: AP(blk, :) = A(blk, :) P -------------------------------------------------------------
     v4d acc[NT];
     if (active) {

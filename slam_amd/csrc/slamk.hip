@@ -331,18 +331,22 @@ Range make_range(const slamk_handle* h, int b0, int cnt)
 }
 
 int run_predict(slamk_handle* h, const Range& rg, const double* qbw, const double* w, const double* acc,
-                const double* dt, hipStream_t st)
+                const double* dt, hipStream_t st, bool frame = false)
 {
+    // frame: the iteration starts an image frame (old_pos = X, depth clamp) before anything else
     // Reads rg.fv.P, leaves the propagated covariance in rg.T: the caller swaps the two buffers of the handle.
     const int B = rg.B, nl = max_nl(h);
     h->last_nl = nl;
     {
         ProfScope ps(h, PC_FEATURE, st);
-        hipLaunchKernelGGL(motion_rows_kernel, dim3((nl + 255) / 256, B), dim3(256), 0, st, rg.fv, qbw, w, dt, nl);
-        if (keep_dense(h, nl))
+        if (keep_dense(h, nl)) {         // the dense F is built between the rows of F and the dynamics
+            if (frame) hipLaunchKernelGGL(frame_begin_kernel, dim3(B), dim3(256), 0, st, rg.fv, -1);
+            hipLaunchKernelGGL(motion_rows_kernel, dim3((nl + 255) / 256, B), dim3(256), 0, st, rg.fv, qbw, w, dt, nl);
             hipLaunchKernelGGL(build_F_kernel, dim3((nl + 63) / 64, (nl + 3) / 4, B), dim3(256), 0, st, rg.fv, qbw, w,
                                dt, rg.Fm, nl);
-        hipLaunchKernelGGL(dynamics_kernel, dim3(B), dim3(256), 0, st, rg.fv, qbw, w, acc, dt);
+            hipLaunchKernelGGL(dynamics_kernel, dim3(B), dim3(256), 0, st, rg.fv, qbw, w, acc, dt);
+        } else
+            hipLaunchKernelGGL(pre_predict_kernel, dim3(B), dim3(256), 0, st, rg.fv, qbw, w, acc, dt, nl, frame ? 1 : 0);
     }
     ProfScope ps(h, PC_STRUCT_PREDICT, st);
     // P <- F P F^T + Q      (calcP, src/slam/main.cpp:526-530, G = I)
@@ -557,29 +561,34 @@ int run_gain_solver(slamk_handle* h, const Range& rg, int nl, int ml, hipStream_
     }
 }
 
+// The gate and the mean update ride in the covariance update kernel when launches are what the step costs (few
+// filters); for a large batch the separate kernel is cheaper than the extra work inside the long kernel.
+bool fuse_apply(int B) { return B <= 256; }
+
 template <int NT>
-int launch_joseph(slamk_handle* h, const Range& rg, int ml, hipStream_t st)
+int launch_joseph(slamk_handle* h, const Range& rg, int ml, int* applied, hipStream_t st)
 {
     const size_t lds = (size_t)(NT * NT + (NT <= 7 ? 2 : 1) * NT + 2) * 256 * sizeof(double);
     { int rc_ = ensure_dynamic_lds(h, reinterpret_cast<const void*>(joseph_kernel<NT>), lds); if (rc_) return rc_; }
     hipLaunchKernelGGL(joseph_kernel<NT>, dim3(rg.B), dim3(512), lds, st, rg.fv, rg.K, h->ldm,
-                       (long long)h->ldn * h->ldm, ml, h->prm.update_form, rg.dx);
+                       (long long)h->ldn * h->ldm, ml, h->prm.update_form, fuse_apply(rg.B) ? (double*)nullptr : rg.dx,
+                       fuse_apply(rg.B) ? 1 : 0, applied);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
 
-int run_joseph(slamk_handle* h, const Range& rg, int nl, int ml, hipStream_t st)
+int run_joseph(slamk_handle* h, const Range& rg, int nl, int ml, int* applied, hipStream_t st)
 {
     ProfScope ps(h, PC_GEMM_COV, st);
     switch (nl / 16) {
-        case 1: return launch_joseph<1>(h, rg, ml, st);
-        case 2: return launch_joseph<2>(h, rg, ml, st);
-        case 3: return launch_joseph<3>(h, rg, ml, st);
-        case 4: return launch_joseph<4>(h, rg, ml, st);
-        case 5: return launch_joseph<5>(h, rg, ml, st);
-        case 6: return launch_joseph<6>(h, rg, ml, st);
-        case 7: return launch_joseph<7>(h, rg, ml, st);
-        case 8: return launch_joseph<8>(h, rg, ml, st);
+        case 1: return launch_joseph<1>(h, rg, ml, applied, st);
+        case 2: return launch_joseph<2>(h, rg, ml, applied, st);
+        case 3: return launch_joseph<3>(h, rg, ml, applied, st);
+        case 4: return launch_joseph<4>(h, rg, ml, applied, st);
+        case 5: return launch_joseph<5>(h, rg, ml, applied, st);
+        case 6: return launch_joseph<6>(h, rg, ml, applied, st);
+        case 7: return launch_joseph<7>(h, rg, ml, applied, st);
+        case 8: return launch_joseph<8>(h, rg, ml, applied, st);
         default: return fail(h, SLAMK_EINVAL, "fused covariance update: n = %d out of range", nl);
     }
 }
@@ -628,7 +637,7 @@ int run_update(slamk_handle* h, const Range& rg, const double* qbw, const double
     }
     if (use_fused_joseph(nl, ml)) {
         // small filters: A = I - K H, A P and the Joseph (or simple) form in one workgroup per filter
-        int rc = run_joseph(h, rg, nl, ml, st);
+        int rc = run_joseph(h, rg, nl, ml, applied, st);      // also dx = K e, the gate and the mean update
         if (rc) return rc;
     } else {
         const double* presym = rg.AP;
@@ -668,7 +677,8 @@ int run_update(slamk_handle* h, const Range& rg, const double* qbw, const double
     // dx = K e, gate, mean update                (main.cpp:228-232)
     if (!use_fused_joseph(nl, ml))      // the fused covariance update has already formed dx
         hipLaunchKernelGGL(gain_kx_kernel, dim3((nl + 15) / 16, B), dim3(256), 0, st, rg.fv, rg.K, ldm, rg.dx, ml);
-    hipLaunchKernelGGL(gain_apply_kernel, dim3(B), dim3(256), 0, st, rg.fv, rg.dx, applied);
+    if (!use_fused_joseph(nl, ml) || !fuse_apply(B))
+        hipLaunchKernelGGL(gain_apply_kernel, dim3(B), dim3(256), 0, st, rg.fv, rg.dx, applied);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -697,8 +707,8 @@ int step_launch(slamk_handle* h, const double* qbw_dev, const double* w_dev, con
         hipStream_t gs = G > 1 ? h->gstreams[g] : st;
         if (G > 1) HIPCHK(h, hipStreamWaitEvent(gs, h->fork, 0));
         const Range rp = make_range(h, b0, b1 - b0);
-        hipLaunchKernelGGL(frame_begin_kernel, dim3(rp.B), dim3(256), 0, gs, rp.fv, -1);
-        rc = run_predict(h, rp, qbw_dev + 4 * (size_t)b0, w_dev + 3 * (size_t)b0, acc_dev + 3 * (size_t)b0, dt_dev + b0, gs);
+        rc = run_predict(h, rp, qbw_dev + 4 * (size_t)b0, w_dev + 3 * (size_t)b0, acc_dev + 3 * (size_t)b0, dt_dev + b0, gs,
+                         true);
         if (!rc)
             rc = run_update(h, after_predict(rp), qbw_dev + 4 * (size_t)b0, (alt_dev ? alt_dev : h->alt_d) + b0,
                             src_dev ? src_dev + 2 * F * b0 : nullptr, refl_dev ? refl_dev + 2 * F * b0 : nullptr,

@@ -21,15 +21,10 @@ namespace slamk {
 
 // Compact rows of F = I + dt A and the diagonal of Q (initQ, src/slam/main.cpp:430-440), at the
 // PRE-predict state.  The three rows of one 3-state block share the group start fgs.
-__global__ void __launch_bounds__(256) motion_rows_kernel(FilterView fv, const double* __restrict__ qbw,
-                                                           const double* __restrict__ w,
-                                                           const double* __restrict__ dtv, int nl)
+__device__ __forceinline__ void motion_row(const FilterView& fv, int b, int j, const double* __restrict__ qbw,
+                                           const double* __restrict__ w, double dt)
 {
-    const int b = blockIdx.y;
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= nl) return;
     const int nf = fv.nf[b], n = 9 + 3 * nf;
-    const double dt = dtv[b];
     double a[3] = {0, 0, 0}, g[3] = {0, 0, 0}, q = 0.0;
     int gs = 0;
     if (j < n) {
@@ -74,6 +69,35 @@ __global__ void __launch_bounds__(256) motion_rows_kernel(FilterView fv, const d
     for (int c = 0; c < 3; ++c) { fv.fa[rb * 3 + c] = a[c]; fv.fg[rb * 3 + c] = g[c]; }
     fv.fgs[rb] = gs;
     fv.qdiag[rb] = q;
+}
+
+__global__ void __launch_bounds__(256) motion_rows_kernel(FilterView fv, const double* __restrict__ qbw,
+                                                           const double* __restrict__ w,
+                                                           const double* __restrict__ dtv, int nl)
+{
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < nl) motion_row(fv, b, j, qbw, w, dtv[b]);
+}
+
+// Everything of an iteration that precedes the covariance propagation, one workgroup per filter: the start of an image
+// frame (old_pos = X, depth clamp; src/slam/main.cpp:168, states.cpp:91-103) when `frame` is set, the compact rows of
+// F at the pre-predict state, then mu += dynamics(mu) dt.  One launch instead of three: what a single small filter
+// pays for is launches, not work.
+__global__ void __launch_bounds__(256) pre_predict_kernel(FilterView fv, const double* __restrict__ qbw,
+                                                           const double* __restrict__ w,
+                                                           const double* __restrict__ acc,
+                                                           const double* __restrict__ dtv, int nl, int frame)
+{
+    const int b = blockIdx.x;
+    if (frame) {
+        frame_begin_filter(fv, b);
+        __syncthreads();                    // the clamped depths are read by the rows of F and by the dynamics
+    }
+    const double dt = dtv[b];
+    for (int j = threadIdx.x; j < nl; j += 256) motion_row(fv, b, j, qbw, w, dt);
+    __syncthreads();                        // F is taken at the state before the dynamics move it
+    dynamics_filter(fv, b, qbw, w, acc, dtv);
 }
 
 struct RowSparse {            // row q: ca[q][0..2] on columns c0..c0+2, cb[q][0..2] on columns cs[q]..cs[q]+2
