@@ -30,6 +30,31 @@
 
 namespace slamk {
 
+// v + (v of the lane selected by the DPP control), lanes without a source add zero.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return v + __hiloint2double(hi, lo);
+}
+
+// Sum of v over the 32 lanes of half-wavefront `half` (0 or 1), returned in every lane of that half: scan within
+// the rows of 16 lanes (row_shr 1, 2, 4, 8), lane 15 of the even row added to the odd row (row_bcast:15), then the
+// totals of lanes 31 and 63 read back.
+__device__ __forceinline__ double half_sum32(double v, int half)
+{
+    v = dpp_add<0x111, 0xf>(v);
+    v = dpp_add<0x112, 0xf>(v);
+    v = dpp_add<0x114, 0xf>(v);
+    v = dpp_add<0x118, 0xf>(v);
+    v = dpp_add<0x142, 0xa>(v);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double t0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 31), __builtin_amdgcn_readlane(lo, 31));
+    const double t1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 63), __builtin_amdgcn_readlane(lo, 63));
+    return half ? t1 : t0;
+}
+
 template <int NT>
 __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double* __restrict__ K, int ldk,
                                                       long long sK, int ml, int form, double* __restrict__ dx,
@@ -127,13 +152,11 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
                     const int l = l0 + c;
                     if (live) lds[((j >> 4) * NT + (l >> 4)) * 256 + tsw(j & 15, l & 15)] = (j == l ? 1.0 : 0.0) - v;
                 }
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) {
-                    x[0] += __shfl_xor(x[0], o); x[1] += __shfl_xor(x[1], o); x[2] += __shfl_xor(x[2], o);
-                    de += __shfl_xor(de, o);
-                }
-                if (l32 == 3) dxs[j] += de;
-                if (l32 < 3) lds[((j >> 4) * NT) * 256 + tsw(j & 15, l32)] -= (l32 == 0 ? x[0] : (l32 == 1 ? x[1] : x[2]));
+                // sums over the 32 lanes of the half-wavefront with data-parallel-primitive moves (no LDS traffic)
+                const double sx0 = half_sum32(x[0], half), sx1 = half_sum32(x[1], half), sx2 = half_sum32(x[2], half);
+                const double sde = half_sum32(de, half);
+                if (l32 == 3) dxs[j] += sde;
+                if (l32 < 3) lds[((j >> 4) * NT) * 256 + tsw(j & 15, l32)] -= (l32 == 0 ? sx0 : (l32 == 1 ? sx1 : sx2));
             }
         }
     }
