@@ -285,11 +285,34 @@ __device__ __forceinline__ void tile_cholesky_forward(double* lds, v4d (&y)[MT],
     };
     // Y^T_j = inv(L_jj) (B^T_j - sum_{k<j} L_jk Y^T_k): a finished tile, lane = column, register = row group,
     // IS the B operand of the next MFMA.
+    // The sum runs in two interleaved chains (even and odd k): consecutive MFMAs of one chain wait for each other.
+    // The operand fragment of the next tile is requested before the products of the current one are issued, so
+    // that its LDS latency passes behind them.
     auto forward_step = [&](int j, v4d acc) {
+        v4d acc2 = (v4d){0.0, 0.0, 0.0, 0.0};
+        double an[4];
+        auto fetch = [&](int k) {                        // row fragment of L_jk (k < j) or of inv(L_jj) (k == j)
+            const double* ta = lds + tile_index(j, k) * 256;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) an[s] = ta[tsw(li, 4 * s + lk)];
+        };
+        fetch(j > 0 ? 0 : j);
 #pragma unroll
         for (int k = 0; k < MT; ++k)
-            if (k < j) acc = tile_mma_regB<false, true>(lds + tile_index(j, k) * 256, y[k], acc, li, lk);
-        return tile_mma_regB<false, false>(lds + tile_index(j, j) * 256, acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
+            if (k < j) {
+                const double a0 = -an[0], a1 = -an[1], a2 = -an[2], a3 = -an[3];
+                fetch(k + 1);                            // k + 1 == j: the diagonal tile
+                v4d& c = (k & 1) ? acc2 : acc;
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, y[k][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, y[k][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, y[k][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, y[k][3], c, 0, 0, 0);
+            }
+        acc += acc2;
+        v4d out = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) out = __builtin_amdgcn_mfma_f64_16x16x4f64(an[s], acc[s], out, 0, 0, 0);
+        return out;
     };
 
     if (wave == 0) {
@@ -509,9 +532,13 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
     double mag = 0.0;                                    // a pivot that was not positive has made K NaN or infinite
 #pragma unroll
     for (int j = MT - 1; j >= 0; --j) {
-        v4d acc = y[j];
+        v4d acc = y[j], acc2 = (v4d){0.0, 0.0, 0.0, 0.0};      // two interleaved chains, as in the forward solve
 #pragma unroll
-        for (int k = j + 1; k < MT; ++k) acc = tile_mma_regB<true, true>(lds + tile_index(k, j) * 256, y[k], acc, li, lk);
+        for (int k = j + 1; k < MT; k += 2) {
+            acc = tile_mma_regB<true, true>(lds + tile_index(k, j) * 256, y[k], acc, li, lk);
+            if (k + 1 < MT) acc2 = tile_mma_regB<true, true>(lds + tile_index(k + 1, j) * 256, y[k + 1], acc2, li, lk);
+        }
+        acc += acc2;
         y[j] = tile_mma_regB<true, false>(lds + tile_index(j, j) * 256, acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
 #pragma unroll
         for (int r = 0; r < 4; ++r) stg[tsw(li, lk + 4 * r)] = y[j][r];
