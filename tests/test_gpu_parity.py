@@ -160,6 +160,31 @@ def test_altimeter_input_without_the_override():
     assert updates >= 5
 
 
+def test_random_configurations_against_oracle():
+    """Seeded sweep over feature counts, reflection fractions, churn patterns and both covariance forms."""
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for case in range(14):
+        nf = int(rng.integers(1, 44))
+        ref = float(rng.choice([0.0, 0.25, 0.5, 0.75, 1.0]))
+        steps = int(rng.integers(10, 28))
+        churn = bool(rng.integers(0, 2))
+        kw = {}
+        if rng.integers(0, 2) and nf > 2:
+            kw.update(drop_at=int(rng.integers(3, steps - 3)), drop_count=int(rng.integers(1, min(nf, 5))))
+        if rng.integers(0, 2):
+            kw.update(add_at=int(rng.integers(3, steps - 2)), add_count=int(rng.integers(1, 6)))
+        st = synth.gen_stream(seed=500 + case, nf=nf, steps=steps, churn=churn, ref_fraction=ref, **kw)
+        so, _ = helpers.run_oracle(st)
+        p = ekf.default_params()
+        p.update_form = int(rng.integers(0, 2))
+        fb = ekf.FilterBatch(max_features=nf + 6, batch=1, params=p)
+        sg = helpers.run_gpu(st, fb)
+        worst = max(worst, compare_snaps(so, sg))
+        fb.close()
+    print("worst rel err over the sweep %.2e" % worst)
+
+
 def test_per_function_parity():
     """F, H, innovation, Cholesky factor and gain of one step against the oracle's functions."""
     st = synth.gen_stream(seed=4, nf=14, steps=7, churn=False)
