@@ -49,3 +49,15 @@ def test_flop_model_is_close_to_dense_formula():
     model = 2 * m**3 / 3 + 2 * n * m * m + 3 * n**3 + n * n * m
     ex = L.slamk_flops_update(n, m, 0)
     assert 0.8 * model < ex < 1.3 * model
+
+
+def test_product_never_touches_the_oracle():
+    """The CPU restatement is test infrastructure: nothing under slam_amd/ or host/ may import, link or name it."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [f for pat in ("slam_amd/*.py", "slam_amd/csrc/*", "host/*.cpp", "host/include/*", "host/Makefile", "include/*.h")
+             for f in glob.glob(os.path.join(root, pat)) if os.path.isfile(f)]
+    assert len(files) > 10
+    for f in files:
+        text = open(f, errors="ignore").read()
+        assert "oracle" not in text.lower() and "orc_" not in text, f
