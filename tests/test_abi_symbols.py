@@ -61,3 +61,15 @@ def test_product_never_touches_the_oracle():
     for f in files:
         text = open(f, errors="ignore").read()
         assert "oracle" not in text.lower() and "orc_" not in text, f
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No CPU fallback: without libslamk.so every entry through the Python face raises."""
+    import pytest
+    from slam_amd import ekf
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libslamk.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ekf.FilterBatch(max_features=4, batch=1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ekf.flops_update(21, 17)
