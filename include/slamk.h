@@ -17,6 +17,15 @@
  *   - Pointers are caller-owned HOST memory unless the name ends in _dev.
  *   - Every function returns 0 or a negative SLAMK_E* code and never exits the process;
  *     slamk_last_error() gives the text.  A handle may be used from one thread at a time.
+ *   - Streams.  The *_dev entry points only queue work on the caller's stream.  The host-pointer entry points
+ *     (set/get, slamk_frame, slamk_predict, slamk_update, slamk_debug_get*) are synchronous; on entry they wait
+ *     for the stream of the handle's most recent *_dev call, so they may follow such a call directly.  A caller
+ *     that spreads *_dev calls of one handle over SEVERAL streams orders them itself (events) and calls slamk_sync
+ *     on each before a host-pointer entry point.
+ *   - Devices.  Handle entry points make the handle's device current for the call and restore the caller's
+ *     current device before they return.  The handle-free entry points (slamk_dgemm_dev, slamk_pre_*,
+ *     slamk_cholesky_inverse_dev, slamk_mfma_f64_probe) run on the device that is
+ *     current in the calling thread; their pointers must belong to it.
  */
 #ifndef SLAMK_H
 #define SLAMK_H
@@ -139,7 +148,10 @@ int slamk_update_dev(slamk_handle* h, const double* qbw_dev, const double* alt_d
  * begin, predict and update in one call, arguments as for the three calls above.  With
  * slamk_set_pipeline_groups(h, g), g > 1, the batch is cut into g ranges of filters that run the chain
  * on internal streams (forked from `stream`, joined into it before the call returns), so kernels of
- * different ranges overlap; results are identical to the three separate calls. */
+ * different ranges overlap; results are identical to the three separate calls.  When slamk_frame (or
+ * slamk_frame_begin_dev) has already begun the frame of every filter since the last predict, the call does not
+ * run the frame begin again: a state override in between (UPDATE_POS, main.cpp:180-185) leaves old_pos at the
+ * value taken before it, as the reference does (:168). */
 int slamk_step_dev(slamk_handle* h, const double* qbw_dev, const double* w_dev, const double* acc_dev,
                    const double* dt_dev, const double* alt_dev, const double* src_dev,
                    const double* refl_dev, int32_t* applied_dev, void* stream);
@@ -149,8 +161,12 @@ int slamk_set_pipeline_groups(slamk_handle* h, int groups);
  * of about ten launches: what a single small filter's latency is made of).  `stream` must not be the null
  * stream; stage timing (slamk_profile_enable) turns graph mode off for the calls it covers. */
 int slamk_set_graph_mode(slamk_handle* h, int on);
-/* Waits for `stream` and returns SLAMK_EREFL / SLAMK_ENOTSPD / SLAMK_OK from the per-filter status words. */
+/* Waits for `stream` and returns SLAMK_EREFL / SLAMK_ENOTSPD / SLAMK_OK from the per-filter status words: the
+ * error text names the first flagged filter and the number of flagged filters, and the words are cleared. */
 int slamk_sync(slamk_handle* h, void* stream);
+/* Copies the per-filter status words (bit 0: reflection rows disagree, bit 1: S not positive definite) to
+ * status[batch] without clearing them; call it before slamk_sync to see every flagged filter. */
+int slamk_read_status(slamk_handle* h, int32_t* status);
 
 /* ---- stage-level entry points: the pieces a row-block sharded large-map filter needs around its
  * own distributed products (slam_amd/sharded.py).  Device pointers, asynchronous on `stream`. ----- */
@@ -184,8 +200,10 @@ int slamk_stage_apply_dev(slamk_handle* h, const double* K_dev, int ldk, int32_t
 int slamk_buffer_dev(slamk_handle* h, int which, double** ptr, int* rows, int* cols, int* ld);
 /* Cholesky of the lower triangle of S (m x m, m a multiple of 16) into L, and into Li the inverses of L's
  * diagonal blocks of 4096 rows (all of inv(L) when m <= 4096); both lower, their strict upper triangles must be
- * zero on entry.  S is overwritten.  slamk_stage_gain_dev takes the pair (L, Li). */
-int slamk_cholesky_inverse_dev(double* S_dev, double* L_dev, double* Li_dev, int m, int ld, void* stream);
+ * zero on entry.  S is overwritten.  slamk_stage_gain_dev takes the pair (L, Li).  status_dev (may be NULL): one
+ * int32 in device memory that gets bit 1 set when S is not positive definite (the caller zeroes and reads it). */
+int slamk_cholesky_inverse_dev(double* S_dev, double* L_dev, double* Li_dev, int m, int ld, int32_t* status_dev,
+                               void* stream);
 
 /* Tuning of the large-matrix path, process-wide (0 = leave as is): the outer panel width of the two-level
  * blocked Cholesky (multiple of 128, default 512) and the rows of the diagonal blocks of L that are inverted for

@@ -50,6 +50,7 @@ SIGNATURES = {
     "slamk_set_pipeline_groups": (C.c_int, [C.c_void_p, C.c_int]),
     "slamk_set_graph_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "slamk_sync": (C.c_int, [_H, _vp]),
+    "slamk_read_status": (C.c_int, [_H, _vp]),
     "slamk_stage_motion_dev": (C.c_int, [_H, _vp, _vp, _vp, _vp, _vp]),
     "slamk_stage_measure_dev": (C.c_int, [_H, _vp, _vp, _vp, _vp, _vp]),
     "slamk_stage_right_dev": (C.c_int, [_H, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp]),
@@ -58,7 +59,7 @@ SIGNATURES = {
     "slamk_stage_gain_dev": (C.c_int, [_H, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "slamk_stage_apply_dev": (C.c_int, [_H, _vp, C.c_int, _vp, _vp]),
     "slamk_buffer_dev": (C.c_int, [_H, C.c_int, C.POINTER(_vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
-    "slamk_cholesky_inverse_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "slamk_cholesky_inverse_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "slamk_pre_euler2qbw_dev": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "slamk_pre_rotate_dev": (C.c_int, [C.POINTER(C.c_double), _vp, _vp, C.c_int, _vp]),
     "slamk_pre_img2body_dev": (C.c_int, [_vp, _vp, C.c_int, _vp]),

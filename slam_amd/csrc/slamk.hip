@@ -66,6 +66,16 @@ struct slamk_handle {
     std::string err;
     hipStream_t stream = nullptr;
     int last_nl = 0, last_ml = 0;
+    // The stream of the last *_dev call whose work may still be running: the host-pointer entry points (null
+    // stream, synchronous) wait for it first, because non-blocking streams are not ordered against the null stream.
+    hipStream_t pending_stream = nullptr;
+    bool pending = false;
+    // slamk_frame has already run the frame begin (old_pos = X, depth clamp) of the coming iteration
+    // (per filter; the fused step runs its own frame begin unless every filter has had one)
+    std::vector<uint8_t> begun;
+    int nbegun = 0;
+    void mark_begun(int b0, int cnt) { for (int b = b0; b < b0 + cnt; ++b) if (!begun[b]) { begun[b] = 1; ++nbegun; } }
+    void clear_begun() { if (nbegun) { std::fill(begun.begin(), begun.end(), 0); nbegun = 0; } }
     // slamk_step_dev: ranges of the batch on streams of their own
     int groups = 1;
     std::vector<hipStream_t> gstreams;
@@ -74,8 +84,8 @@ struct slamk_handle {
     // slamk_step_dev in graph mode: captured launch sequences, keyed by everything baked into the launches
     bool debug = false;                    // materialise dense F, H and L for slamk_debug_get*
     bool graph_mode = false;
-    struct GraphKey {
-        const void* p[8]; const double* P; int nl, ml, nfmax, form;
+    struct GraphKey {      // everything that is baked into a captured launch sequence
+        const void* p[8]; const double* P; int nl, ml, nfmax, form, debug, outer_block, inverse_block, frame_begin;
         bool operator==(const GraphKey& o) const { return memcmp(this, &o, sizeof *this) == 0; }
     };
     struct GraphEntry { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; };
@@ -105,6 +115,39 @@ int fail(slamk_handle* h, int code, const char* fmt, ...)
         hipError_t e_ = (call);                                                                    \
         if (e_ != hipSuccess) return fail(h, SLAMK_EHIP, "%s: %s", #call, hipGetErrorString(e_));  \
     } while (0)
+
+// Makes the handle's device current for one entry point and restores the caller's device afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err;
+    explicit DeviceGuard(int dev)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) err = hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define ENTER(h)                                                                                                   \
+    DeviceGuard dg_((h)->device);                                                                                  \
+    if (dg_.err != hipSuccess) return fail(h, SLAMK_EHIP, "hipSetDevice(%d): %s", (h)->device, hipGetErrorString(dg_.err))
+
+// Entry of a host-pointer (synchronous, null-stream) entry point: work queued by an earlier *_dev call is complete
+// before it touches the handle's buffers.
+int wait_pending(slamk_handle* h)
+{
+    if (h->pending) {
+        HIPCHK(h, hipStreamSynchronize(h->pending_stream));
+        h->pending = false;
+    }
+    return 0;
+}
+#define ENTER_HOST(h)                                                                                              \
+    ENTER(h);                                                                                                      \
+    { int rc_ = wait_pending(h); if (rc_) return rc_; }
+inline void note_stream(slamk_handle* h, void* stream) { h->pending_stream = (hipStream_t)stream; h->pending = true; }
 
 // Stage categories reported by slamk_profile_read.
 enum ProfCat {
@@ -687,7 +730,7 @@ int run_update(slamk_handle* h, const Range& rg, const double* qbw, const double
 // Leaves the propagated covariance in the T buffer: the caller swaps P and T.
 int step_launch(slamk_handle* h, const double* qbw_dev, const double* w_dev, const double* acc_dev, const double* dt_dev,
                 const double* alt_dev, const double* src_dev, const double* refl_dev, int32_t* applied_dev,
-                hipStream_t st, int groups)
+                hipStream_t st, int groups, bool frame_begin)
 {
     const int G = std::max(1, std::min(groups, h->B));
     if ((int)h->gstreams.size() < G && G > 1) {
@@ -702,21 +745,27 @@ int step_launch(slamk_handle* h, const double* qbw_dev, const double* w_dev, con
     const size_t F = h->F;
     if (G > 1) HIPCHK(h, hipEventRecord(h->fork, st));
     int rc = 0;
-    for (int g = 0; g < G && !rc; ++g) {
+    for (int g = 0; g < G; ++g) {
         const int b0 = (int)((long long)h->B * g / G), b1 = (int)((long long)h->B * (g + 1) / G);
         hipStream_t gs = G > 1 ? h->gstreams[g] : st;
-        if (G > 1) HIPCHK(h, hipStreamWaitEvent(gs, h->fork, 0));
-        const Range rp = make_range(h, b0, b1 - b0);
-        rc = run_predict(h, rp, qbw_dev + 4 * (size_t)b0, w_dev + 3 * (size_t)b0, acc_dev + 3 * (size_t)b0, dt_dev + b0, gs,
-                         true);
-        if (!rc)
-            rc = run_update(h, after_predict(rp), qbw_dev + 4 * (size_t)b0, (alt_dev ? alt_dev : h->alt_d) + b0,
-                            src_dev ? src_dev + 2 * F * b0 : nullptr, refl_dev ? refl_dev + 2 * F * b0 : nullptr,
-                            applied_dev ? applied_dev + b0 : nullptr, gs);
-        if (G > 1) {
-            HIPCHK(h, hipEventRecord(h->gdone[g], gs));
-            HIPCHK(h, hipStreamWaitEvent(st, h->gdone[g], 0));
+        hipError_t he = hipSuccess;
+        if (G > 1) he = hipStreamWaitEvent(gs, h->fork, 0);
+        if (!rc && he == hipSuccess) {
+            const Range rp = make_range(h, b0, b1 - b0);
+            rc = run_predict(h, rp, qbw_dev + 4 * (size_t)b0, w_dev + 3 * (size_t)b0, acc_dev + 3 * (size_t)b0, dt_dev + b0,
+                             gs, frame_begin);
+            if (!rc)
+                rc = run_update(h, after_predict(rp), qbw_dev + 4 * (size_t)b0, (alt_dev ? alt_dev : h->alt_d) + b0,
+                                src_dev ? src_dev + 2 * F * b0 : nullptr, refl_dev ? refl_dev + 2 * F * b0 : nullptr,
+                                applied_dev ? applied_dev + b0 : nullptr, gs);
         }
+        // every forked stream is joined back into `st`, also after a failure: the caller's stream never ends up
+        // ahead of work that this call queued
+        if (G > 1 && he == hipSuccess) {
+            he = hipEventRecord(h->gdone[g], gs);
+            if (he == hipSuccess) he = hipStreamWaitEvent(st, h->gdone[g], 0);
+        }
+        if (he != hipSuccess && !rc) rc = fail(h, SLAMK_EHIP, "step: stream fork/join: %s", hipGetErrorString(he));
     }
     return rc;
 }
@@ -766,8 +815,9 @@ int slamk_create(const slamk_params* p, int max_features, int batch, int device,
     h->ldn = pad16(9 + 3 * h->F);
     h->ldm = pad16(1 + 6 * h->F);
     h->hf.resize(batch);
+    h->begun.assign(batch, 0);
     *out = h;
-    HIPCHK(h, hipSetDevice(device));
+    ENTER(h);
     const size_t B = batch, F = h->F, ldn = h->ldn, ldm = h->ldm;
     FilterView& v = h->fv;
     v.B = batch; v.F = h->F; v.ldn = h->ldn; v.ldm = h->ldm;
@@ -804,7 +854,7 @@ int slamk_create(const slamk_params* p, int max_features, int batch, int device,
 int slamk_destroy(slamk_handle* h)
 {
     if (!h) return SLAMK_EINVAL;
-    (void)hipSetDevice(h->device);
+    DeviceGuard dg_(h->device);
     (void)hipDeviceSynchronize();
     for (void* p : h->allocs) (void)hipFree(p);
     for (auto& g : h->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
@@ -826,7 +876,7 @@ int slamk_destroy(slamk_handle* h)
 int slamk_set_state(slamk_handle* h, int b, const double* X, const double* V, const double* bias)
 {
     CHECK_B(h, b);
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER_HOST(h);
     if (X) HIPCHK(h, hipMemcpy(h->fv.X + 3 * b, X, 24, hipMemcpyHostToDevice));
     if (V) HIPCHK(h, hipMemcpy(h->fv.V + 3 * b, V, 24, hipMemcpyHostToDevice));
     if (bias) HIPCHK(h, hipMemcpy(h->fv.bias + 3 * b, bias, 24, hipMemcpyHostToDevice));
@@ -836,7 +886,7 @@ int slamk_set_state(slamk_handle* h, int b, const double* X, const double* V, co
 int slamk_get_state(slamk_handle* h, int b, double* X, double* V, double* bias)
 {
     CHECK_B(h, b);
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER_HOST(h);
     if (X) HIPCHK(h, hipMemcpy(X, h->fv.X + 3 * b, 24, hipMemcpyDeviceToHost));
     if (V) HIPCHK(h, hipMemcpy(V, h->fv.V + 3 * b, 24, hipMemcpyDeviceToHost));
     if (bias) HIPCHK(h, hipMemcpy(bias, h->fv.bias + 3 * b, 24, hipMemcpyDeviceToHost));
@@ -847,7 +897,7 @@ int slamk_set_cov(slamk_handle* h, int b, const double* P, int n, int ld)
 {
     CHECK_B(h, b);
     if (!P || n != 9 + 3 * h->hf[b].nf || ld < n) return fail(h, SLAMK_EINVAL, "set_cov: n=%d does not match nf=%d", n, h->hf[b].nf);
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER_HOST(h);
     double* dst = h->fv.P + (size_t)b * h->ldn * h->ldn;
     HIPCHK(h, hipMemset(dst, 0, (size_t)h->ldn * h->ldn * sizeof(double)));
     HIPCHK(h, hipMemcpy2D(dst, h->ldn * sizeof(double), P, ld * sizeof(double), n * sizeof(double), n, hipMemcpyHostToDevice));
@@ -858,7 +908,7 @@ int slamk_get_cov(slamk_handle* h, int b, double* P, int n, int ld)
 {
     CHECK_B(h, b);
     if (!P || n != 9 + 3 * h->hf[b].nf || ld < n) return fail(h, SLAMK_EINVAL, "get_cov: n=%d does not match nf=%d", n, h->hf[b].nf);
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER_HOST(h);
     const double* src = h->fv.P + (size_t)b * h->ldn * h->ldn;
     HIPCHK(h, hipMemcpy2D(P, ld * sizeof(double), src, h->ldn * sizeof(double), n * sizeof(double), n, hipMemcpyDeviceToHost));
     return SLAMK_OK;
@@ -873,7 +923,7 @@ int slamk_set_features(slamk_handle* h, int b, int nf, const int32_t* id, const 
     CHECK_B(h, b);
     if (nf < 0 || nf > h->F) return fail(h, SLAMK_ECAPACITY, "set_features: nf=%d exceeds max_features=%d", nf, h->F);
     if (nf && (!id || !pib || !anchor || !q0 || !pib0 || !is_ref)) return fail(h, SLAMK_EINVAL, "set_features: null array");
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER_HOST(h);
     const int F = h->F;
     HostFilter& f = h->hf[b];
     f.nf = nf;
@@ -897,7 +947,7 @@ int slamk_get_features(slamk_handle* h, int b, int* nf_out, int32_t* id, double*
                        double* pib0, uint8_t* is_ref)
 {
     CHECK_B(h, b);
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER_HOST(h);
     const HostFilter& f = h->hf[b];
     const int F = h->F, nf = f.nf;
     if (nf_out) *nf_out = nf;
@@ -1038,13 +1088,14 @@ static int apply_frame(slamk_handle* h, int b0, int cnt, const FramePlan& p, con
     HIPCHK(h, hipMemcpy(rg.fv.msrc, ms.data(), ms.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(rg.fv.mrefl, mr.data(), mr.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(h, hipDeviceSynchronize());
+    h->mark_begun(b0, cnt);
     return SLAMK_OK;
 }
 
 int slamk_frame(slamk_handle* h, int b, const slamk_match* matches, int nmatch, const double quat[4])
 {
     if (!h || nmatch < 0 || (nmatch && !matches) || !quat) return SLAMK_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER_HOST(h);
     FramePlan plan;
     if (b >= 0) {
         CHECK_B(h, b);
@@ -1067,7 +1118,7 @@ int slamk_set_frame_values(slamk_handle* h, int b, const double* src2, const dou
 {
     CHECK_B(h, b);
     if (!src2 || !refl2) return SLAMK_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER_HOST(h);
     const int F = h->F, nf = h->hf[b].nf;
     std::vector<double> ms(2 * F, 0.0), mr(2 * F, 0.0);
     for (int i = 0; i < nf; ++i) {
@@ -1083,9 +1134,11 @@ int slamk_set_frame_values(slamk_handle* h, int b, const double* src2, const dou
 int slamk_frame_begin_dev(slamk_handle* h, void* stream)
 {
     if (!h) return SLAMK_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
+    note_stream(h, stream);
     hipLaunchKernelGGL(frame_begin_kernel, dim3(h->B), dim3(256), 0, (hipStream_t)stream, h->fv, -1);
     HIPCHK(h, hipGetLastError());
+    h->mark_begun(0, h->B);
     return SLAMK_OK;
 }
 
@@ -1093,11 +1146,14 @@ int slamk_predict_dev(slamk_handle* h, const double* qbw_dev, const double* w_de
                       const double* dt_dev, void* stream)
 {
     if (!h || !qbw_dev || !w_dev || !acc_dev || !dt_dev) return SLAMK_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     { int rc_ = ensure_workspaces(h); if (rc_) return rc_; }
+    note_stream(h, stream);
     int rc = run_predict(h, make_range(h, 0, h->B), qbw_dev, w_dev, acc_dev, dt_dev, (hipStream_t)stream);
+    if (rc) return rc;                 // P still names the buffer that holds the covariance
     std::swap(h->fv.P, h->T);          // T is whichever of the two covariance-sized buffers is not P
-    return rc;
+    h->clear_begun();
+    return SLAMK_OK;
 }
 
 int slamk_update_dev(slamk_handle* h, const double* qbw_dev, const double* alt_dev, const double* src_dev,
@@ -1105,8 +1161,9 @@ int slamk_update_dev(slamk_handle* h, const double* qbw_dev, const double* alt_d
 {
     if (!h || !qbw_dev) return SLAMK_EINVAL;
     if (!alt_dev && !h->prm.use_alt_override) return fail(h, SLAMK_EINVAL, "update: alt required without alt_override");
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     { int rc_ = ensure_workspaces(h); if (rc_) return rc_; }
+    note_stream(h, stream);
     return run_update(h, make_range(h, 0, h->B), qbw_dev, alt_dev ? alt_dev : h->alt_d, src_dev, refl_dev, applied_dev,
                       (hipStream_t)stream);
 }
@@ -1121,9 +1178,14 @@ int slamk_step_dev(slamk_handle* h, const double* qbw_dev, const double* w_dev, 
 {
     if (!h || !qbw_dev || !w_dev || !acc_dev || !dt_dev) return SLAMK_EINVAL;
     if (!alt_dev && !h->prm.use_alt_override) return fail(h, SLAMK_EINVAL, "step: alt required without alt_override");
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     { int rc_ = ensure_workspaces(h); if (rc_) return rc_; }
     hipStream_t st = (hipStream_t)stream;
+    note_stream(h, stream);
+    // slamk_frame / slamk_frame_begin_dev of this iteration have already set old_pos and clamped the depths; a
+    // state override between them and this call (UPDATE_POS, src/slam/main.cpp:180-185) must not move old_pos,
+    // which the reference takes before the override (:168)
+    const bool frame_begin = h->nbegun < h->B;
     if (h->graph_mode && !h->prof_on && st != nullptr) {
         // replay (or first capture) the launch sequence as one hipGraph: one submission per iteration
         slamk_handle::GraphKey key;
@@ -1131,6 +1193,8 @@ int slamk_step_dev(slamk_handle* h, const double* qbw_dev, const double* w_dev, 
         const void* ptrs[8] = {qbw_dev, w_dev, acc_dev, dt_dev, alt_dev, src_dev, refl_dev, applied_dev};
         memcpy(key.p, ptrs, sizeof ptrs);
         key.P = h->fv.P; key.nl = max_nl(h); key.ml = max_ml(h); key.form = h->prm.update_form;
+        key.debug = h->debug; key.outer_block = chol_outer_block(); key.inverse_block = INV_BS;
+        key.frame_begin = frame_begin;
         for (const auto& f : h->hf) key.nfmax = std::max(key.nfmax, f.nf);
         slamk_handle::GraphEntry* hit = nullptr;
         for (auto& g : h->graphs)
@@ -1143,21 +1207,33 @@ int slamk_step_dev(slamk_handle* h, const double* qbw_dev, const double* w_dev, 
             slamk_handle::GraphEntry e;
             e.key = key;
             HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            int rc = step_launch(h, qbw_dev, w_dev, acc_dev, dt_dev, alt_dev, src_dev, refl_dev, applied_dev, st, 1);
+            e.graph = nullptr;
+            int rc = step_launch(h, qbw_dev, w_dev, acc_dev, dt_dev, alt_dev, src_dev, refl_dev, applied_dev, st, 1,
+                                 frame_begin);
             hipError_t ce = hipStreamEndCapture(st, &e.graph);
-            if (rc) return rc;
-            if (ce != hipSuccess) return fail(h, SLAMK_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
-            HIPCHK(h, hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
+            if (rc || ce != hipSuccess) {
+                if (e.graph) (void)hipGraphDestroy(e.graph);
+                return rc ? rc : fail(h, SLAMK_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+            }
+            ce = hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0);
+            if (ce != hipSuccess) {
+                (void)hipGraphDestroy(e.graph);
+                return fail(h, SLAMK_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(ce));
+            }
             h->graphs.push_back(e);
             hit = &h->graphs.back();
         }
         HIPCHK(h, hipGraphLaunch(hit->exec, st));
         std::swap(h->fv.P, h->T);
+        h->clear_begun();
         return SLAMK_OK;
     }
-    int rc = step_launch(h, qbw_dev, w_dev, acc_dev, dt_dev, alt_dev, src_dev, refl_dev, applied_dev, st, h->groups);
+    int rc = step_launch(h, qbw_dev, w_dev, acc_dev, dt_dev, alt_dev, src_dev, refl_dev, applied_dev, st, h->groups,
+                         frame_begin);
+    if (rc) return rc;                 // P still names the buffer that holds the last complete covariance
     std::swap(h->fv.P, h->T);
-    return rc;
+    h->clear_begun();
+    return SLAMK_OK;
 }
 
 int slamk_set_graph_mode(slamk_handle* h, int on)
@@ -1177,24 +1253,35 @@ int slamk_set_pipeline_groups(slamk_handle* h, int groups)
 int slamk_sync(slamk_handle* h, void* stream)
 {
     if (!h) return SLAMK_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    if (h->pending && h->pending_stream == (hipStream_t)stream) h->pending = false;
     std::vector<int> st(h->B);
     HIPCHK(h, hipMemcpy(st.data(), h->fv.status, h->B * sizeof(int), hipMemcpyDeviceToHost));
+    int first = -1, nbad = 0;
     for (int b = 0; b < h->B; ++b)
-        if (st[b]) {
-            HIPCHK(h, hipMemset(h->fv.status, 0, h->B * sizeof(int)));
-            if (st[b] & 1)
-                return fail(h, SLAMK_EREFL, "filter %d: reflection rows of H, R and e disagree (zero reflection observation or innovation)", b);
-            return fail(h, SLAMK_ENOTSPD, "filter %d: S = H P H^T + R is not positive definite (Cholesky pivot <= 0)", b);
-        }
+        if (st[b]) { if (first < 0) first = b; ++nbad; }
+    if (first < 0) return SLAMK_OK;
+    // the words are cleared once they have been reported: the text names the first filter and how many there are,
+    // slamk_read_status (before this call) gives all of them
+    HIPCHK(h, hipMemset(h->fv.status, 0, h->B * sizeof(int)));
+    if (st[first] & 1)
+        return fail(h, SLAMK_EREFL, "filter %d (%d of %d filters flagged): reflection rows of H, R and e disagree (zero reflection observation or innovation)", first, nbad, h->B);
+    return fail(h, SLAMK_ENOTSPD, "filter %d (%d of %d filters flagged): S = H P H^T + R is not positive definite (Cholesky pivot <= 0)", first, nbad, h->B);
+}
+
+int slamk_read_status(slamk_handle* h, int32_t* status)
+{
+    if (!h || !status) return SLAMK_EINVAL;
+    ENTER_HOST(h);
+    HIPCHK(h, hipMemcpy(status, h->fv.status, h->B * sizeof(int), hipMemcpyDeviceToHost));
     return SLAMK_OK;
 }
 
 int slamk_predict(slamk_handle* h, const double* qbw, const double* w, const double* acc, const double* dt)
 {
     if (!h || !qbw || !w || !acc || !dt) return SLAMK_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER_HOST(h);
     { int rc_ = ensure_workspaces(h); if (rc_) return rc_; }
     const size_t B = h->B;
     HIPCHK(h, hipMemcpy(h->qbw_d, qbw, B * 32, hipMemcpyHostToDevice));
@@ -1202,8 +1289,9 @@ int slamk_predict(slamk_handle* h, const double* qbw, const double* w, const dou
     HIPCHK(h, hipMemcpy(h->acc_d, acc, B * 24, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->dt_d, dt, B * 8, hipMemcpyHostToDevice));
     int rc = run_predict(h, make_range(h, 0, h->B), h->qbw_d, h->w_d, h->acc_d, h->dt_d, 0);
-    std::swap(h->fv.P, h->T);
     if (rc) return rc;
+    std::swap(h->fv.P, h->T);
+    h->clear_begun();
     HIPCHK(h, hipDeviceSynchronize());
     return SLAMK_OK;
 }
@@ -1212,7 +1300,7 @@ int slamk_update(slamk_handle* h, const double* qbw, const double* alt, int* app
 {
     if (!h || !qbw) return SLAMK_EINVAL;
     if (!alt && !h->prm.use_alt_override) return fail(h, SLAMK_EINVAL, "update: alt required without alt_override");
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER_HOST(h);
     { int rc_ = ensure_workspaces(h); if (rc_) return rc_; }
     const size_t B = h->B;
     HIPCHK(h, hipMemcpy(h->qbw_d, qbw, B * 32, hipMemcpyHostToDevice));
@@ -1229,7 +1317,8 @@ int slamk_stage_motion_dev(slamk_handle* h, const double* qbw_dev, const double*
                            const double* dt_dev, void* stream)
 {
     if (!h || !qbw_dev || !w_dev || !acc_dev || !dt_dev) return SLAMK_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
+    note_stream(h, stream);
     { int rc_ = ensure_workspaces(h); if (rc_) return rc_; }
     hipStream_t st = (hipStream_t)stream;
     const int nl = max_nl(h);
@@ -1246,7 +1335,8 @@ int slamk_stage_measure_dev(slamk_handle* h, const double* qbw_dev, const double
                             const double* refl_dev, void* stream)
 {
     if (!h || !qbw_dev) return SLAMK_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
+    note_stream(h, stream);
     { int rc_ = ensure_workspaces(h); if (rc_) return rc_; }
     hipStream_t st = (hipStream_t)stream;
     const int nl = max_nl(h), ml = max_ml(h);
@@ -1276,7 +1366,8 @@ int slamk_stage_right_dev(slamk_handle* h, int which, const double* In_dev, int 
     RowSparse M; int mrows; const double* diag;
     if (!h || !In_dev || !Out_dev || rows < 0 || !stage_operator(h, which, &M, &mrows, &diag)) return SLAMK_EINVAL;
     if (ldi < max_nl(h) || ldo < mrows) return fail(h, SLAMK_EINVAL, "stage_right: leading dimensions too small");
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
+    note_stream(h, stream);
     if (rows) launch_right(M, In_dev, ldi, 0, Out_dev, ldo, 0, rows, mrows, 1, (hipStream_t)stream);
     HIPCHK(h, hipGetLastError());
     return SLAMK_OK;
@@ -1289,7 +1380,8 @@ int slamk_stage_left_dev(slamk_handle* h, int which, int row0, int rows, const d
     if (!h || !In_dev || !Out_dev || row0 < 0 || rows < 0 || cols < 0 || !stage_operator(h, which, &M, &mrows, &diag))
         return SLAMK_EINVAL;
     if (ldi < cols || ldo < cols) return fail(h, SLAMK_EINVAL, "stage_left: leading dimensions too small");
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
+    note_stream(h, stream);
     const int r = std::max(0, std::min(rows, mrows - row0));     // rows past the operator are left to the caller (zero)
     if (r && cols) {
         M.ca += 3 * (size_t)row0; M.cb += 3 * (size_t)row0; M.cs += row0;
@@ -1313,7 +1405,8 @@ int slamk_stage_eye_minus_kh_dev(slamk_handle* h, const double* K_dev, int ldk, 
     if (!h || !K_dev || !A_dev || row0 < 0 || rows < 0) return SLAMK_EINVAL;
     const int nl = max_nl(h), ml = max_ml(h);
     if (ldk < ml || lda < nl) return fail(h, SLAMK_EINVAL, "stage_eye_minus_kh: leading dimensions too small");
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
+    note_stream(h, stream);
     hipStream_t st = (hipStream_t)stream;
     if (rows) {
         hipLaunchKernelGGL(eye_minus_kh_kernel, dim3((nl + 63) / 64, (rows + 4 * STRUCT_RPW - 1) / (4 * STRUCT_RPW), 1),
@@ -1334,7 +1427,8 @@ int slamk_stage_gain_dev(slamk_handle* h, double* W_dev, int rows, int m, int ld
         (m & 15))
         return SLAMK_EINVAL;
     if (ld < m || ldli < m) return fail(h, SLAMK_EINVAL, "stage_gain: leading dimensions too small");
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
+    note_stream(h, stream);
     int rc = gain_from_factor(h, W_dev, Y_dev, K_dev, KR_dev, ld, 0, L_dev, Li_dev, ldli, 0, r_dev, 0, rows, m, 1,
                               (hipStream_t)stream);
     return rc ? rc : SLAMK_OK;
@@ -1343,7 +1437,8 @@ int slamk_stage_gain_dev(slamk_handle* h, double* W_dev, int rows, int m, int ld
 int slamk_stage_apply_dev(slamk_handle* h, const double* K_dev, int ldk, int32_t* applied_dev, void* stream)
 {
     if (!h || !K_dev || ldk < 1) return SLAMK_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
+    note_stream(h, stream);
     hipStream_t st = (hipStream_t)stream;
     const int nl = max_nl(h), ml = max_ml(h);
     hipLaunchKernelGGL(gain_kx_kernel, dim3((nl + 15) / 16, h->B), dim3(256), 0, st, h->fv, K_dev, ldk, h->dx, ml);
@@ -1368,11 +1463,13 @@ int slamk_buffer_dev(slamk_handle* h, int which, double** ptr, int* rows, int* c
     return SLAMK_OK;
 }
 
-int slamk_cholesky_inverse_dev(double* S_dev, double* L_dev, double* Li_dev, int m, int ld, void* stream)
+int slamk_cholesky_inverse_dev(double* S_dev, double* L_dev, double* Li_dev, int m, int ld, int32_t* status_dev,
+                               void* stream)
 {
     if (!S_dev || !L_dev || !Li_dev || m < 16 || (m & 15) || ld < m) return SLAMK_EINVAL;
     static thread_local slamk_handle scratch_handle;   // error text / profiling sink for the handle-free call
-    return cholesky_inverse(&scratch_handle, S_dev, L_dev, Li_dev, ld, (long long)ld * m, 1, m, nullptr, (hipStream_t)stream);
+    return cholesky_inverse(&scratch_handle, S_dev, L_dev, Li_dev, ld, (long long)ld * m, 1, m, status_dev,
+                            (hipStream_t)stream);
 }
 
 // ---- stream pre-processing filters, batched --------------------------------------------------------------
@@ -1410,8 +1507,10 @@ int slamk_pre_fir_dev(const double* coeffs_dev, int order, const double* x_dev, 
 int slamk_set_debug(slamk_handle* h, int on)
 {
     if (!h) return SLAMK_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER_HOST(h);
     h->debug = on != 0;
+    for (auto& g : h->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+    h->graphs.clear();                 // captured sequences were recorded without (or with) the dense F, H, L kernels
     return ensure_workspaces(h);
 }
 
@@ -1419,7 +1518,7 @@ int slamk_debug_get(slamk_handle* h, int b, double* H, double* L, double* K, dou
 {
     CHECK_B(h, b);
     if ((H || L) && !h->debug) return fail(h, SLAMK_EINVAL, "debug_get: H and L are only kept after slamk_set_debug(h, 1)");
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER_HOST(h);
     const int n = 9 + 3 * h->hf[b].nf, m = h->hf[b].m();
     const size_t ldn = h->ldn, ldm = h->ldm;
     if (H) HIPCHK(h, hipMemcpy2D(H, n * 8, h->Hm + b * ldm * ldn, ldn * 8, n * 8, m, hipMemcpyDeviceToHost));
@@ -1433,7 +1532,7 @@ int slamk_debug_get_F(slamk_handle* h, int b, double* F)
 {
     CHECK_B(h, b);
     if (!h->debug) return fail(h, SLAMK_EINVAL, "debug_get_F: F is only kept after slamk_set_debug(h, 1)");
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER_HOST(h);
     const int n = 9 + 3 * h->hf[b].nf;
     const size_t ldn = h->ldn;
     HIPCHK(h, hipMemcpy2D(F, n * 8, h->Fm + b * ldn * ldn, ldn * 8, n * 8, n, hipMemcpyDeviceToHost));
@@ -1494,7 +1593,7 @@ int slamk_profile_enable(slamk_handle* h, int on)
 int slamk_profile_read(slamk_handle* h, double* ms, int* count, int ncat)
 {
     if (!h || !ms || !count || ncat < PC_COUNT) return SLAMK_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     HIPCHK(h, hipDeviceSynchronize());
     for (int i = 0; i < ncat; ++i) { ms[i] = 0; count[i] = 0; }
     for (auto& r : h->prof_recs) {

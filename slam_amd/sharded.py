@@ -118,7 +118,7 @@ class HipBackend:
 
     def cholesky_inverse(self, S, Lm, Li):
         rc = self.L.slamk_cholesky_inverse_dev(S.data_ptr(), Lm.data_ptr(), Li.data_ptr(), S.shape[0], S.stride(0),
-                                               self.sptr)
+                                               None, self.sptr)
         if rc:
             raise RuntimeError("slamk_cholesky_inverse_dev failed: %d" % rc)
 
