@@ -24,7 +24,7 @@
  *     on each before a host-pointer entry point.
  *   - Devices.  Handle entry points make the handle's device current for the call and restore the caller's
  *     current device before they return.  The handle-free entry points (slamk_dgemm_dev, slamk_pre_*,
- *     slamk_cholesky_inverse_dev, slamk_mfma_f64_probe) run on the device that is
+ *     slamk_cholesky_inverse_dev, slamk_stage_gain_static_dev, slamk_mfma_f64_probe) run on the device that is
  *     current in the calling thread; their pointers must belong to it.
  */
 #ifndef SLAMK_H
@@ -193,6 +193,15 @@ int slamk_stage_eye_minus_kh_dev(slamk_handle* h, const double* K_dev, int ldk, 
 int slamk_stage_gain_dev(slamk_handle* h, double* W_dev, int rows, int m, int ld, const double* L_dev,
                          const double* Li_dev, int ldli, double* Y_dev, double* K_dev, double* KR_dev,
                          const double* r_dev, void* stream);
+/* No counterpart in the reference.  slamk_stage_gain_dev for callers that cannot allocate device memory (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the workspace Y is taken from an
+ * array that lives inside the library's code object (32 MiB per GPU, held until the process ends) instead of from
+ * the caller, and the call allocates and frees nothing.  Same arguments and results otherwise.  Limit:
+ * rows * ld <= 4 Mi doubles (SLAMK_ECAPACITY beyond).  All calls on one GPU share that array: calls that overlap
+ * on one GPU (different streams or threads) race. */
+int slamk_stage_gain_static_dev(slamk_handle* h, double* W_dev, int rows, int m, int ld, const double* L_dev,
+                                const double* Li_dev, int ldli, double* K_dev, double* KR_dev, const double* r_dev,
+                                void* stream);
 /* dx = K e with the caller's gain K (n x m, leading dimension ldk), gate and mean update (main.cpp:228-232). */
 int slamk_stage_apply_dev(slamk_handle* h, const double* K_dev, int ldk, int32_t* applied_dev, void* stream);
 /* Device address and shape of one of the handle's matrices (filter 0): which = 0 F, 1 H, 2 innovation e,

@@ -57,6 +57,7 @@ SIGNATURES = {
     "slamk_stage_left_dev": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp]),
     "slamk_stage_eye_minus_kh_dev": (C.c_int, [_H, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp]),
     "slamk_stage_gain_dev": (C.c_int, [_H, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "slamk_stage_gain_static_dev": (C.c_int, [_H, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "slamk_stage_apply_dev": (C.c_int, [_H, _vp, C.c_int, _vp, _vp]),
     "slamk_buffer_dev": (C.c_int, [_H, C.c_int, C.POINTER(_vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "slamk_cholesky_inverse_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),

@@ -25,6 +25,12 @@
 
 using namespace slamk;
 
+// Workspace of the entry points that may not allocate (slamk_stage_gain_static_dev): every GPU the library runs
+// on holds its own copy of this array, at its own address, until the process ends.  In host code the name below is
+// only a stand-in for the symbol: the device address comes from hipGetSymbolAddress (static_scratch()).
+constexpr size_t STATIC_SCRATCH_DOUBLES = (size_t)4 << 20;      // 32 MiB
+static __device__ __align__(256) double slamk_static_scratch[STATIC_SCRATCH_DOUBLES];
+
 namespace {
 
 inline int pad16(int x) { return (x + 15) / 16 * 16; }
@@ -148,6 +154,27 @@ int wait_pending(slamk_handle* h)
     ENTER(h);                                                                                                      \
     { int rc_ = wait_pending(h); if (rc_) return rc_; }
 inline void note_stream(slamk_handle* h, void* stream) { h->pending_stream = (hipStream_t)stream; h->pending = true; }
+
+// Device address of slamk_static_scratch on the CURRENT device, looked up once per device.
+hipError_t static_scratch(double** out)
+{
+    constexpr int MAXDEV = 64;
+    static double* ptrs[MAXDEV] = {};
+    static std::mutex mtx;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= MAXDEV) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mtx);
+    if (!ptrs[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(slamk_static_scratch));
+        if (e != hipSuccess) return e;
+        ptrs[dev] = static_cast<double*>(p);
+    }
+    *out = ptrs[dev];
+    return hipSuccess;
+}
 
 // Stage categories reported by slamk_profile_read.
 enum ProfCat {
@@ -818,6 +845,7 @@ int slamk_create(const slamk_params* p, int max_features, int batch, int device,
     h->begun.assign(batch, 0);
     *out = h;
     ENTER(h);
+    { double* sp_ = nullptr; HIPCHK(h, static_scratch(&sp_)); }   // set-up of the no-allocation entry points on this device
     const size_t B = batch, F = h->F, ldn = h->ldn, ldm = h->ldm;
     FilterView& v = h->fv;
     v.B = batch; v.F = h->F; v.ldn = h->ldn; v.ldm = h->ldm;
@@ -1430,6 +1458,27 @@ int slamk_stage_gain_dev(slamk_handle* h, double* W_dev, int rows, int m, int ld
     ENTER(h);
     note_stream(h, stream);
     int rc = gain_from_factor(h, W_dev, Y_dev, K_dev, KR_dev, ld, 0, L_dev, Li_dev, ldli, 0, r_dev, 0, rows, m, 1,
+                              (hipStream_t)stream);
+    return rc ? rc : SLAMK_OK;
+}
+
+// slamk_stage_gain_dev with the workspace Y in the library's static device array: no allocation of any kind.
+int slamk_stage_gain_static_dev(slamk_handle* h, double* W_dev, int rows, int m, int ld, const double* L_dev,
+                                const double* Li_dev, int ldli, double* K_dev, double* KR_dev, const double* r_dev,
+                                void* stream)
+{
+    if (!h || !W_dev || !L_dev || !Li_dev || !K_dev || !KR_dev || !r_dev || rows < 16 || (rows & 15) || m < 16 || (m & 15))
+        return SLAMK_EINVAL;
+    if (ld < m || ldli < m) return fail(h, SLAMK_EINVAL, "stage_gain_static: leading dimensions too small");
+    if ((size_t)rows * (size_t)ld > STATIC_SCRATCH_DOUBLES)
+        return fail(h, SLAMK_ECAPACITY, "stage_gain_static: rows * ld = %zu doubles exceed the static workspace of %zu",
+                    (size_t)rows * (size_t)ld, STATIC_SCRATCH_DOUBLES);
+    ENTER(h);
+    note_stream(h, stream);
+    double* Y = nullptr;
+    HIPCHK(h, static_scratch(&Y));       // cached after the first call on this device; the array's name is never passed on
+    // Y needs no clearing: every column block of Y is written in full before the solves read it
+    int rc = gain_from_factor(h, W_dev, Y, K_dev, KR_dev, ld, 0, L_dev, Li_dev, ldli, 0, r_dev, 0, rows, m, 1,
                               (hipStream_t)stream);
     return rc ? rc : SLAMK_OK;
 }
