@@ -143,3 +143,25 @@ def test_fir_ring_buffer_equals_causal_convolution():
     for order, n in ((1, 4), (5, 3), (16, 200)):
         c, x = rng.standard_normal(order), rng.standard_normal(n)
         assert np.allclose(orc.fir(c, x), np.convolve(x, c)[:n], rtol=1e-13, atol=1e-13)
+
+
+# ---- committed end-to-end fixtures (oracle/gen_stream_goldens.py) -------------------------------------------
+import pytest   # noqa: E402
+
+import helpers  # noqa: E402
+
+
+class _S:       # the part of a synth.Stream that run_oracle reads besides the inputs
+    def __init__(self, init_pos):
+        self.init_pos = init_pos
+
+
+@pytest.mark.parametrize("nf", [5, 20, 32])
+def test_oracle_reproduces_the_committed_stream_fixtures(nf):
+    """An edit of the oracle (or another compiler) that moves its results shows up here: the parity target of the
+    GPU tests is the committed data, not whatever the oracle computes today."""
+    fx = helpers.FixtureStream(os.path.join(G, "stream_nf%d.npz" % nf))
+    snaps, _ = helpers.run_oracle(_S(fx.init_pos), inp=fx.inp)
+    worst = helpers.compare_with_fixture(fx.expected(), snaps, 1e-12)
+    assert len({len(s["ids"]) for s in snaps}) > 1          # the stream has insertions and deletions
+    print("nf=%d worst deviation from the fixture %.2e" % (nf, worst))

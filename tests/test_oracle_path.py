@@ -134,3 +134,30 @@ def test_bench_cpu_baseline_leg_runs_on_a_small_sample():
     r = bench.cpu_baseline(st, steps, 5, 1, 4, budget_s=0.05, max_filters=2)
     assert r["kind"] == "port" and r["cores"] == 1 and r["unit"] == "EKF updates/s" and r["value"] > 0
     assert "sample" in r
+
+
+def test_numpy_algebra_oracle_matches_the_c_loops():
+    """oracle/numpy_oracle.py (LAPACK products and LU solve around the C per-feature parts, used for the 2000-feature
+    golden) against orc_step's own dense loops on a stream with churn."""
+    from oracle import numpy_oracle as npo
+    st = synth.gen_stream(seed=2, nf=40, steps=13, churn=True, drop_at=6, drop_count=2, add_at=9, add_count=3)
+    inp = helpers.stream_inputs(st, 7)
+    fs = []
+    for mode in (0, 1):
+        f = orc.Filter()
+        f.X = st.init_pos
+        f.update_features(inp[0][5], inp[0][1])
+        f.old_pos[:] = f.X
+        for k in range(1, len(inp)):
+            u, quat, ang, acc, dt, matches = inp[k]
+            s = orc.make_sensors(quat=quat, acc=acc, ang=ang)
+            if mode == 0:
+                rc, _, _ = f.step(u, s, dt, matches)
+                assert rc == 0
+            else:
+                npo.step(f, u, s, dt, matches)
+        fs.append(f)
+    assert fs[0].ids() == fs[1].ids()
+    assert helpers.rel_err(fs[1].P, fs[0].P) < 1e-12
+    assert helpers.entry_err(fs[1].P, fs[0].P) < 1e-10      # entries scaled by sqrt(P_ii P_jj): the bias block is 1e-4
+    assert helpers.rel_err(fs[1].state_vector(), fs[0].state_vector()) < 1e-12
