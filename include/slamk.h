@@ -233,8 +233,10 @@ int slamk_pre_fir_dev(const double* coeffs_dev, int order, const double* x_dev, 
 /* Introspection is opt-in: after slamk_set_debug(h, 1) every predict/update also writes the dense F, H and
  * the Cholesky factor L, which the products themselves never need. */
 int slamk_set_debug(slamk_handle* h, int on);
-/* Copies of the last update's intermediates of filter b (NULL = skip): H m x n, S's Cholesky
- * factor L m x m (lower), K n x m, innovation e[m]. */
+/* Copies of the last update's intermediates of filter b (NULL = skip): H m x n, K n x m and the innovation e[m]
+ * in the measurement order of this header (altitude first); L m x m (lower) is the Cholesky factor of S in the
+ * order the library computes in, feature rows first and the altitude row LAST (rows and columns of S rotated by
+ * one): the factor of a permuted matrix is not a permutation of the factor. */
 int slamk_debug_get(slamk_handle* h, int b, double* H, double* L, double* K, double* e);
 /* Dense motion Jacobian of the last predict, n x n. */
 int slamk_debug_get_F(slamk_handle* h, int b, double* F);

@@ -14,7 +14,8 @@ struct FilterView {
     double *X, *V, *bias, *old_pos;             // [B][3]
     int *nf, *m;                                // [B]
     double *pib, *anchor, *q0, *pib0;           // [B][3|3|4|2][F]
-    int *isref, *rowoff;                        // [B][F]   measurement row of the feature's first row
+    int *isref, *rowoff;                        // [B][F]   measurement row of the feature's first row (feature rows
+                                                //          start at row 0, the altitude row is row m - 1)
     double *msrc, *mrefl;                       // [B][2][F] kept frame, slot order
     double *P;                                  // [B][ldn][ldn]
     // measurement rows in compact form: entries in columns 0..2, entries in columns cs..cs+2
@@ -208,7 +209,7 @@ __global__ void __launch_bounds__(256) frame_begin_kernel(FilterView fv, int b_o
 //   View subtract / toMat                           src/ARC/view.cpp:3-47
 //   initR                                           src/slam/main.cpp:449-476
 // pib0Hat is evaluated at old_pos, the Jacobians and ppbHat at the post-predict X (:376-386).
-// One thread per feature slot; thread (0,0) of each filter also writes row 0, and all threads
+// One thread per feature slot; thread (0,0) of each filter also writes the altitude row, and all threads
 // fill the padding rows [m, ml) with e = 0, r = 1, H = 0.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) measure_kernel(FilterView fv, const double* __restrict__ qbw,
@@ -228,12 +229,16 @@ __global__ void __launch_bounds__(64) measure_kernel(FilterView fv, const double
     const double X[3] = {fv.X[3 * b], fv.X[3 * b + 1], fv.X[3 * b + 2]};
 
     if (i == 0) {                                           // altitude row, :351-354, :452
+        // The reference puts it first (row 0 of H, R and e); here it is the LAST row, m - 1, behind the feature
+        // rows, so that those start on a 16-row tile boundary.  The order of the measurement rows does not change
+        // K e, K H or K R K^T; slamk_debug_get hands rows out in the reference's order.
+        const int ia = m - 1;
         const double a = fv.use_alt_override ? fv.alt_override : alt[b];
-        e[0] = a - (-X[2]);
-        rd[0] = 0.15 * fv.R0;
-        ha[0] = 0.0; ha[1] = 0.0; ha[2] = -1.0;
-        hb[0] = hb[1] = hb[2] = 0.0;
-        hcs[0] = -1;
+        e[ia] = a - (-X[2]);
+        rd[ia] = 0.15 * fv.R0;
+        ha[3 * ia] = 0.0; ha[3 * ia + 1] = 0.0; ha[3 * ia + 2] = -1.0;
+        hb[3 * ia] = hb[3 * ia + 1] = hb[3 * ia + 2] = 0.0;
+        hcs[ia] = -1;
     }
     for (int q = m + i; q < ml; q += gridDim.x * 64) {      // padding rows
         e[q] = 0.0; rd[q] = 1.0; hcs[q] = -1;

@@ -395,7 +395,16 @@ struct SolverLds {
     static constexpr int TILES = MT * (MT + 1) / 2 + EXTRA_TILES;
 };
 
-template <int MT>
+// BORDER: the launch covers 16 MT rows of S as tiles and one more row, the altitude row, which the library keeps
+// LAST (row m - 1).  For a filter with m - 1 == 16 MT that row is factored as a border of the tiled block,
+//     S = [S_ff s; s^T sigma],  L = [L_ff 0; l^T lambda],  l = inv(L_ff) s,  lambda^2 = sigma - l^T l,
+// and carried through the two solves on the vector pipeline:
+//     y_a = (w_a - Y_f l) / lambda,   k_a = y_a / lambda,   K_f = (Y_f - k_a l^T) inv(L_ff),
+// instead of costing a whole tile row and column for one measurement.  The altitude row of H is -e_2^T
+// (src/slam/main.cpp:354), so s = -(row 2 of W_f)^T, hence l = -(row 2 of Y_f)^T: the forward solve has already
+// produced it; w_a = -P[:, 2], sigma = P[2][2] + r_a.  Filters of the batch whose altitude row lies inside the tiles
+// (m - 1 < 16 MT) take the plain path.
+template <int MT, bool BORDER>
 __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double* __restrict__ K, double* __restrict__ KR,
                                                            double* __restrict__ L, long long sM, long long sNM, int NT)
 {
@@ -523,13 +532,59 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
     });
     if (Lb) store_offdiag_tiles<MT>(lds, Lb, ldm, wave, lane);
 
+    // ---- the altitude row as a border of the factored block -----------------------------------------------
+    double k_alt = 0.0;                                  // K[16 blk + li][M], the same in the four lane groups
+    bool border = false;
+    if constexpr (BORDER) {
+        border = (fv.m[b] - 1 == M);                     // uniform over the workgroup
+        if (border) {
+            double* lvec = scratch;                      // [M]: l; the diagonal-tile scratch tile is free by now
+            const double w_a = has_blk ? -Pb[(long long)min(16 * blk + li, nl - 1) * ldn + 2] : 0.0;
+            const double sigma = Pb[2 * ldn + 2] + rd[M];
+            if (blk == 0 && li == 2) {                   // row 2 of Y_f: lane = column 2 of the wavefront's Y^T tiles
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) lvec[16 * j + lk + 4 * r] = -y[j][r];
+            }
+            __syncthreads();
+            double d = 0.0, ll = 0.0;
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double lq = lvec[16 * j + lk + 4 * r];
+                    d = fma(y[j][r], lq, d);             // this lane group's share of (Y_f l)_a
+                    ll = fma(lq, lq, ll);
+                }
+            d += __shfl_xor(d, 16); d += __shfl_xor(d, 32);
+            ll += __shfl_xor(ll, 16); ll += __shfl_xor(ll, 32);
+            const double lam2 = sigma - ll;
+            if (!(lam2 > 0.0) && tid == 0) atomicOr(fv.status + b, 2);     // S was not positive definite
+            const double ilam = rsqrt_nr(lam2);
+            k_alt = has_blk ? (w_a - d) * ilam * ilam : 0.0;
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[j][r] = fma(-k_alt, lvec[16 * j + lk + 4 * r], y[j][r]);
+            if (Lb && wave == 1) {                       // the factor's last row, for introspection
+                for (int q = lane; q < M; q += 64) Lb[(long long)M * ldm + q] = lvec[q];
+                if (lane == 0) Lb[(long long)M * ldm + M] = lam2 * ilam;
+            }
+        }
+    }
+
     // ---- K^T_j = inv(L_jj)^T (Y^T_j - sum_{k>j} L_kj^T K^T_k),  j = MT-1 .. 0 -----------------------------
     if (!has_blk) return;
+    if (border && lk == 0) {                             // the altitude column of K
+        K[(long long)b * sNM + (long long)(16 * blk + li) * ldm + M] = k_alt;
+        if (KR) KR[(long long)b * sNM + (long long)(16 * blk + li) * ldm + M] = k_alt * rd[M];
+    }
     // Every finished tile of K leaves at once, through the wavefront's staging tile (128-byte runs per row): its
     // stores drain while the products of the next tile run.
     double* Kb = K + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li;
     double* KRb = KR ? KR + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li : nullptr;
-    double mag = 0.0;                                    // a pivot that was not positive has made K NaN or infinite
+    double mag = fabs(k_alt);                            // a pivot that was not positive has made K NaN or infinite
 #pragma unroll
     for (int j = MT - 1; j >= 0; --j) {
         v4d acc = y[j], acc2 = (v4d){0.0, 0.0, 0.0, 0.0};      // two interleaved chains, as in the forward solve

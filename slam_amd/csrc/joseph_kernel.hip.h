@@ -17,6 +17,9 @@
 //              = sum_k AP(I, k) A(J, k)   A operand from LDS, B operand = the A fragments
 //              + sum_q K(I, q) r_q K(J, q) K staged through LDS in chunks of 16 columns
 //            and stores every tile together with its mirror image.
+// The altitude row is the LAST measurement row of a filter (row m - 1).  `mlc` = the columns of K that the chunk
+// loop covers (a multiple of 16); a filter whose altitude column is column mlc itself (m - 1 == mlc) adds that
+// column's term k_a r_a k_a^T on the vector pipeline instead of paying a seventeenth-of-a-chunk MFMA pass for it.
 // Row blocks are dealt to wavefronts so that the two wavefronts sharing a SIMD (w and w + 4) own
 // columns of 8 - t and t + 1 tiles.
 #pragma once
@@ -57,7 +60,7 @@ __device__ __forceinline__ double half_sum32(double v, int half)
 
 template <int NT>
 __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double* __restrict__ K, int ldk,
-                                                      long long sK, int ml, int form, double* __restrict__ dx,
+                                                      long long sK, int mlc, int form, double* __restrict__ dx,
                                                       int apply, int* __restrict__ applied)
 {
     extern __shared__ double lds[];                     // NT * NT tiles of 256 doubles (tile (I, J) at I * NT + J)
@@ -65,6 +68,7 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
     double* kst = lds + NT * NT * 256;                  // + KBUF * NT tiles: 16-column chunks of K
     double* rds = kst + KBUF * NT * 256;                // + 256: diagonal of R
     double* dxs = rds + 256;                            // + 128: dx = K e
+    double* kalt = dxs + 128;                           // + 128: the altitude column of K
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -74,6 +78,8 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
     double* Pb = fv.P + (long long)b * ldn * ldn;
     const double* Kb = K + (long long)b * sK;
     const int nf = fv.nf[b];
+    const int ia = fv.m[b] - 1;                         // altitude row of H / column of K
+    const bool border = (ia == mlc);                    // not covered by the chunk loop
 
     // P tiles of this wavefront go to registers first: their latency hides behind phase A
     constexpr int PT = (NT * NT + 7) / 8;
@@ -89,18 +95,31 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
 
     // ---- phase A: A = I - K H in LDS -------------------------------------------------------------------
     for (int t = tid; t < NT * NT * 256; t += 512) lds[t] = 0.0;
-    for (int t = tid; t < ml; t += 512) rds[t] = fv.rdiag[(long long)b * fv.ldm + t];
-    if (tid < 16 * NT) dxs[tid] = 0.0;
+    for (int t = tid; t < mlc; t += 512) rds[t] = fv.rdiag[(long long)b * fv.ldm + t];
+    // The altitude row (H row ia = (ha, 0), main.cpp:354) is taken by one thread per row j of A, ahead of the
+    // feature rows: A[j][0..2] = I - K[j][ia] ha, and its share of dx_j = sum_q K[j][q] e[q] (main.cpp:228).
+    double ka_own = 0.0;
+    if (tid < 16 * NT) {
+        ka_own = Kb[(long long)tid * ldk + ia];
+        kalt[tid] = ka_own;
+        dxs[tid] = ka_own * fv.e[(long long)b * fv.ldm + ia];
+    }
     __syncthreads();
-    if (tid < 16 * NT) lds[((tid >> 4) * (NT + 1)) * 256 + tsw(tid & 15, tid & 15)] = 1.0;
+    if (tid < 16 * NT) {
+        lds[((tid >> 4) * (NT + 1)) * 256 + tsw(tid & 15, tid & 15)] = 1.0;
+        const double* hal = fv.ha + ((long long)b * fv.ldm + ia) * 3;
+        double* row = lds + ((tid >> 4) * NT) * 256;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) row[tsw(tid & 15, c)] = (tid == c ? 1.0 : 0.0) - ka_own * hal[c];
+    }
     __syncthreads();
     {
         const double* hb = fv.hb + (long long)b * fv.ldm * 3;
         const double* ha = fv.ha + (long long)b * fv.ldm * 3;
         const int half = lane >> 5, l32 = lane & 31;
         // lane = feature i: columns 6 + 3 i .. + 2 from its 4 or 6 measurement rows, and its share of the
-        // position columns 0..2 (summed over the lanes; lane 0 also carries the altitude row 0)
-        for (int i0 = 0; i0 < max(nf, 1); i0 += 32) {      // at least once: the altitude row exists without features
+        // position columns 0..2 (summed over the lanes)
+        for (int i0 = 0; i0 < nf; i0 += 32) {
             const int i = i0 + l32;
             const bool live = i < nf;
             const int row0 = live ? fv.rowoff[(long long)b * fv.F + i] : 0;
@@ -112,21 +131,17 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
                 h[t] = on ? hb[(long long)row0 * 3 + t] : 0.0;
                 g[t] = on ? ha[(long long)row0 * 3 + t] : 0.0;
             }
-            const bool alt = (i == 0);
-            const double g0 = alt ? ha[0] : 0.0, g1 = alt ? ha[1] : 0.0, g2 = alt ? ha[2] : 0.0;
             const double* ev = fv.e + (long long)b * fv.ldm;
-            const double e0 = alt ? ev[0] : 0.0;
             double ef[6];
 #pragma unroll
             for (int t = 0; t < 6; ++t) ef[t] = (live && (t < 4 || six)) ? ev[row0 + t] : 0.0;
             const int l0 = 6 + 3 * i;
             // the gain entries of the next pass are requested before this pass is worked on
-            double kn[7];
+            double kn[6];
             auto fetch = [&](int pass) {
                 const double* kr = Kb + (long long)(pass * 16 + wave * 2 + half) * ldk;
 #pragma unroll
                 for (int t = 0; t < 6; ++t) kn[t] = (live && (t < 4 || six)) ? kr[row0 + t] : 0.0;
-                kn[6] = alt ? kr[0] : 0.0;
             };
             fetch(0);
 #pragma unroll
@@ -136,10 +151,9 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
                 double k[6];
 #pragma unroll
                 for (int t = 0; t < 6; ++t) k[t] = kn[t];
-                const double ka = kn[6];
                 if (pass + 1 < NT && NT <= 7) fetch(pass + 1);      // (no registers to spare for it at NT = 8)
-                double x[3] = {ka * g0, ka * g1, ka * g2};
-                double de = ka * e0;                     // this lane's share of dx_j = sum_q K[j][q] e[q]   (main.cpp:228)
+                double x[3] = {0.0, 0.0, 0.0};
+                double de = 0.0;                         // this lane's share of dx_j = sum_q K[j][q] e[q]   (main.cpp:228)
 #pragma unroll
                 for (int t = 0; t < 6; ++t) de = fma(k[t], ef[t], de);
 #pragma unroll
@@ -280,7 +294,7 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
 #pragma unroll
             for (int r = 0; r < 4; ++r) pre[r] = ksrc[r * r4];
         }
-        const int nchunk = ml / 16;
+        const int nchunk = mlc / 16;
         for (int c = 0; c < nchunk; ++c) {
             double* kc = kst + (KBUF == 2 ? (c & 1) * NT * 256 : 0);
             if (loader) {
@@ -317,6 +331,15 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
                 }
             }
             if (KBUF == 1) __syncthreads();      // with two buffers the next store goes to the other one
+        }
+        if (border && active) {                  // + k_a r_a k_a^T for the altitude column, which no chunk holds
+            const double cj = kalt[16 * J + li] * fv.rdiag[(long long)b * fv.ldm + ia];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (J + t < NT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[t][r] = fma(kalt[16 * (J + t) + lk + 4 * r], cj, o[t][r]);
+                }
         }
     }
 #if JOSEPH_STOP == 5

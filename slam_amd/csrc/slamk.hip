@@ -245,11 +245,25 @@ int max_ml(const slamk_handle* h)
     return pad16(m);
 }
 
+int max_m(const slamk_handle* h)
+{
+    int m = 1;
+    for (const auto& f : h->hf) m = std::max(m, f.m());
+    return m;
+}
+
 constexpr int SOLVER_MAX_MT = 11, SOLVER_MAX_NT = 8;
 
-bool use_fused_solver(int nl, int ml) { return nl <= 16 * SOLVER_MAX_NT && ml <= 16 * SOLVER_MAX_MT; }
-// the fused covariance update only needs P in LDS (and ml <= 256 for its copy of diag R)
-bool use_fused_joseph(int nl, int ml) { return nl <= 16 * SOLVER_MAX_NT && ml <= 256; }
+// The altitude row is the last measurement row.  When the feature rows of the largest filter fill their 16-row
+// tiles exactly (m - 1 a multiple of 16), the per-filter kernels cover only those tiles and take the altitude row
+// as a border (one row / column on the vector pipeline) instead of a tile row of its own.
+bool alt_is_border(int m) { return m > 1 && (m - 1) % 16 == 0; }
+// measurement rows covered by 16-row tiles in the per-filter kernels
+int tiled_rows(int m) { return alt_is_border(m) ? m - 1 : pad16(m); }
+
+bool use_fused_solver(int nl, int m) { return nl <= 16 * SOLVER_MAX_NT && tiled_rows(m) <= 16 * SOLVER_MAX_MT; }
+// the fused covariance update only needs P in LDS (and at most 256 tiled measurement rows for its copy of diag R)
+bool use_fused_joseph(int nl, int m) { return nl <= 16 * SOLVER_MAX_NT && tiled_rows(m) <= 256; }
 
 // Workspaces beyond P, T and K.  The per-filter fused kernels keep every intermediate in LDS, so a batch of small
 // filters never touches these: they are allocated when a layout or the debug switch first needs them.
@@ -259,10 +273,10 @@ enum { WS_GAIN = 1,     // W, Y, KR, S, L, Li: gain by blocked Cholesky + GEMMs
 
 int ensure_workspaces(slamk_handle* h)
 {
-    const int nl = max_nl(h), ml = max_ml(h);
+    const int nl = max_nl(h), mm = max_m(h);
     int need = 0;
-    if (!use_fused_solver(nl, ml)) need |= WS_GAIN;
-    if (!use_fused_joseph(nl, ml)) need |= WS_COV;
+    if (!use_fused_solver(nl, mm)) need |= WS_GAIN;
+    if (!use_fused_joseph(nl, mm)) need |= WS_COV;
     if (h->debug) need |= WS_DENSE;
     need &= ~h->have_ws;
     if (!need) return 0;
@@ -302,12 +316,13 @@ int push_layout(slamk_handle* h, int b0, int cnt)
     const HostFilter& f = h->hf[b0];
     const int F = h->F;
     std::vector<int> isr((size_t)cnt * F, 0), ro((size_t)cnt * F, 0);
-    int row = 1;
+    int row = 0;                               // feature rows first, the altitude row last (row m - 1)
     for (int i = 0; i < f.nf; ++i) {
         isr[i] = f.isref[i];
         ro[i] = row;
         row += f.isref[i] ? 6 : 4;
     }
+    row += 1;
     for (int c = 1; c < cnt; ++c) {
         std::copy(isr.begin(), isr.begin() + F, isr.begin() + (size_t)c * F);
         std::copy(ro.begin(), ro.begin() + F, ro.begin() + (size_t)c * F);
@@ -599,42 +614,52 @@ int run_cholesky_inverse(slamk_handle* h, const Range& rg, int ml, hipStream_t s
     return cholesky_inverse(h, rg.S, rg.L, rg.Li, h->ldm, (long long)h->ldm * h->ldm, rg.B, ml, rg.fv.status, st);
 }
 
-template <int MT>
+template <int MT, bool BORDER>
 int launch_gain_solver(slamk_handle* h, const Range& rg, int nl, double* Lout, hipStream_t st)
 {
     const size_t lds = (size_t)SolverLds<MT>::TILES * 256 * sizeof(double);
-    { int rc_ = ensure_dynamic_lds(h, reinterpret_cast<const void*>(gain_solver_kernel<MT>), lds); if (rc_) return rc_; }
+    { int rc_ = ensure_dynamic_lds(h, reinterpret_cast<const void*>(gain_solver_kernel<MT, BORDER>), lds); if (rc_) return rc_; }
     const long long sM = (long long)h->ldm * h->ldm, sNM = (long long)h->ldn * h->ldm;
-    hipLaunchKernelGGL(gain_solver_kernel<MT>, dim3(rg.B), dim3(512), lds, st, rg.fv, rg.K, (double*)nullptr, Lout, sM, sNM,
-                       nl / 16);
+    hipLaunchKernelGGL((gain_solver_kernel<MT, BORDER>), dim3(rg.B), dim3(512), lds, st, rg.fv, rg.K, (double*)nullptr, Lout,
+                       sM, sNM, nl / 16);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
 
-int run_gain_solver(slamk_handle* h, const Range& rg, int nl, int ml, hipStream_t st)
+template <bool BORDER>
+int run_gain_solver_b(slamk_handle* h, const Range& rg, int nl, int mt, double* Lout, hipStream_t st)
+{
+    switch (mt) {
+        case 1: return launch_gain_solver<1, BORDER>(h, rg, nl, Lout, st);
+        case 2: return launch_gain_solver<2, BORDER>(h, rg, nl, Lout, st);
+        case 3: return launch_gain_solver<3, BORDER>(h, rg, nl, Lout, st);
+        case 4: return launch_gain_solver<4, BORDER>(h, rg, nl, Lout, st);
+        case 5: return launch_gain_solver<5, BORDER>(h, rg, nl, Lout, st);
+        case 6: return launch_gain_solver<6, BORDER>(h, rg, nl, Lout, st);
+        case 7: return launch_gain_solver<7, BORDER>(h, rg, nl, Lout, st);
+        case 8: return launch_gain_solver<8, BORDER>(h, rg, nl, Lout, st);
+        case 9: return launch_gain_solver<9, BORDER>(h, rg, nl, Lout, st);
+        case 10: return launch_gain_solver<10, BORDER>(h, rg, nl, Lout, st);
+        case 11: return launch_gain_solver<11, BORDER>(h, rg, nl, Lout, st);
+        default: return fail(h, SLAMK_EINVAL, "gain solver: %d measurement tiles out of range", mt);
+    }
+}
+
+// mm = measurement rows of the largest filter of the batch
+int run_gain_solver(slamk_handle* h, const Range& rg, int nl, int mm, hipStream_t st)
 {
     ProfScope ps(h, PC_SOLVER, st);
     double* Lout = h->debug ? rg.L : nullptr;         // the factor is only kept for slamk_debug_get
-    switch (ml / 16) {
-        case 1: return launch_gain_solver<1>(h, rg, nl, Lout, st);
-        case 2: return launch_gain_solver<2>(h, rg, nl, Lout, st);
-        case 3: return launch_gain_solver<3>(h, rg, nl, Lout, st);
-        case 4: return launch_gain_solver<4>(h, rg, nl, Lout, st);
-        case 5: return launch_gain_solver<5>(h, rg, nl, Lout, st);
-        case 6: return launch_gain_solver<6>(h, rg, nl, Lout, st);
-        case 7: return launch_gain_solver<7>(h, rg, nl, Lout, st);
-        case 8: return launch_gain_solver<8>(h, rg, nl, Lout, st);
-        case 9: return launch_gain_solver<9>(h, rg, nl, Lout, st);
-        case 10: return launch_gain_solver<10>(h, rg, nl, Lout, st);
-        case 11: return launch_gain_solver<11>(h, rg, nl, Lout, st);
-        default: return fail(h, SLAMK_EINVAL, "gain solver: m = %d out of range", ml);
-    }
+    const int mt = tiled_rows(mm) / 16;
+    return alt_is_border(mm) ? run_gain_solver_b<true>(h, rg, nl, mt, Lout, st)
+                             : run_gain_solver_b<false>(h, rg, nl, mt, Lout, st);
 }
 
 // The gate and the mean update ride in the covariance update kernel when launches are what the step costs (few
 // filters); for a large batch the separate kernel is cheaper than the extra work inside the long kernel.
 bool fuse_apply(int B) { return B <= 256; }
 
+// mlc = the columns of K walked in 16-column chunks (tiled_rows of the largest filter)
 template <int NT>
 int launch_joseph(slamk_handle* h, const Range& rg, int ml, int* applied, hipStream_t st)
 {
@@ -667,7 +692,7 @@ int run_update(slamk_handle* h, const Range& rg, const double* qbw, const double
                int* applied, hipStream_t st)
 {
     const int B = rg.B, ldn = h->ldn, ldm = h->ldm;
-    const int nl = max_nl(h), ml = max_ml(h);
+    const int nl = max_nl(h), ml = max_ml(h), mm = max_m(h);
     const long long sN = (long long)ldn * ldn, sNM = (long long)ldn * ldm, sM = (long long)ldm * ldm;
     h->last_nl = nl; h->last_ml = ml;
     int nfmax = 0;
@@ -686,16 +711,16 @@ int run_update(slamk_handle* h, const Range& rg, const double* qbw, const double
     const RowSparse MH{rg.fv.ha, rg.fv.hb, rg.fv.hcs, ldm, 0};
     {
     ProfScope ps(h, PC_STRUCT_GAIN, st);
-    if (!use_fused_solver(nl, ml)) {     // the fused solver forms W and S in LDS itself
+    if (!use_fused_solver(nl, mm)) {     // the fused solver forms W and S in LDS itself
         // W = P H^T                                  (calcK, src/slam/main.cpp:545)
         launch_right(MH, rg.fv.P, ldn, sN, rg.W, ldm, sNM, nl, ml, B, st);
         // S = H W + R, lower part                    (:541-543)
         launch_left<true>(MH, rg.W, ldm, sNM, rg.S, ldm, sM, rg.fv.rdiag, ldm, ml, ml, B, st);
     }
     }
-    if (use_fused_solver(nl, ml)) {
+    if (use_fused_solver(nl, mm)) {
         // small filters: S = L L^T and K = W L^-T L^-1 (plus K R) in one workgroup per filter
-        int rc = run_gain_solver(h, rg, nl, ml, st);
+        int rc = run_gain_solver(h, rg, nl, mm, st);
         if (rc) return rc;
     } else {
         // S = L L^T, Li = inv(L)
@@ -705,9 +730,9 @@ int run_update(slamk_handle* h, const Range& rg, const double* qbw, const double
         rc = gain_from_factor(h, rg.W, rg.Y, rg.K, rg.KR, ldm, sNM, rg.L, rg.Li, ldm, sM, rg.fv.rdiag, ldm, nl, ml, B, st);
         if (rc) return rc;
     }
-    if (use_fused_joseph(nl, ml)) {
+    if (use_fused_joseph(nl, mm)) {
         // small filters: A = I - K H, A P and the Joseph (or simple) form in one workgroup per filter
-        int rc = run_joseph(h, rg, nl, ml, applied, st);      // also dx = K e, the gate and the mean update
+        int rc = run_joseph(h, rg, nl, tiled_rows(mm), applied, st);      // also dx = K e, the gate and the mean update
         if (rc) return rc;
     } else {
         const double* presym = rg.AP;
@@ -745,9 +770,9 @@ int run_update(slamk_handle* h, const Range& rg, const double* qbw, const double
     }
     ProfScope ps_tail(h, PC_FEATURE, st);
     // dx = K e, gate, mean update                (main.cpp:228-232)
-    if (!use_fused_joseph(nl, ml))      // the fused covariance update has already formed dx
+    if (!use_fused_joseph(nl, mm))      // the fused covariance update has already formed dx
         hipLaunchKernelGGL(gain_kx_kernel, dim3((nl + 15) / 16, B), dim3(256), 0, st, rg.fv, rg.K, ldm, rg.dx, ml);
-    if (!use_fused_joseph(nl, ml) || !fuse_apply(B))
+    if (!use_fused_joseph(nl, mm) || !fuse_apply(B))
         hipLaunchKernelGGL(gain_apply_kernel, dim3(B), dim3(256), 0, st, rg.fv, rg.dx, applied);
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -1220,7 +1245,7 @@ int slamk_step_dev(slamk_handle* h, const double* qbw_dev, const double* w_dev, 
         memset(&key, 0, sizeof key);
         const void* ptrs[8] = {qbw_dev, w_dev, acc_dev, dt_dev, alt_dev, src_dev, refl_dev, applied_dev};
         memcpy(key.p, ptrs, sizeof ptrs);
-        key.P = h->fv.P; key.nl = max_nl(h); key.ml = max_ml(h); key.form = h->prm.update_form;
+        key.P = h->fv.P; key.nl = max_nl(h); key.ml = max_m(h); key.form = h->prm.update_form;
         key.debug = h->debug; key.outer_block = chol_outer_block(); key.inverse_block = INV_BS;
         key.frame_begin = frame_begin;
         for (const auto& f : h->hf) key.nfmax = std::max(key.nfmax, f.nf);
@@ -1570,10 +1595,29 @@ int slamk_debug_get(slamk_handle* h, int b, double* H, double* L, double* K, dou
     ENTER_HOST(h);
     const int n = 9 + 3 * h->hf[b].nf, m = h->hf[b].m();
     const size_t ldn = h->ldn, ldm = h->ldm;
-    if (H) HIPCHK(h, hipMemcpy2D(H, n * 8, h->Hm + b * ldm * ldn, ldn * 8, n * 8, m, hipMemcpyDeviceToHost));
+    // The library keeps the altitude row last; H, K and e go out in the reference's order (altitude first).
+    std::vector<double> tmp;
+    if (H) {
+        tmp.resize((size_t)m * n);
+        HIPCHK(h, hipMemcpy2D(tmp.data(), n * 8, h->Hm + b * ldm * ldn, ldn * 8, n * 8, m, hipMemcpyDeviceToHost));
+        for (int q = 0; q < m; ++q)
+            memcpy(H + (size_t)q * n, tmp.data() + (size_t)(q == 0 ? m - 1 : q - 1) * n, (size_t)n * 8);
+    }
     if (L) HIPCHK(h, hipMemcpy2D(L, m * 8, h->L + b * ldm * ldm, ldm * 8, m * 8, m, hipMemcpyDeviceToHost));
-    if (K) HIPCHK(h, hipMemcpy2D(K, m * 8, h->K + b * ldn * ldm, ldm * 8, m * 8, n, hipMemcpyDeviceToHost));
-    if (e) HIPCHK(h, hipMemcpy(e, h->fv.e + b * ldm, m * 8, hipMemcpyDeviceToHost));
+    if (K) {
+        tmp.resize((size_t)n * m);
+        HIPCHK(h, hipMemcpy2D(tmp.data(), m * 8, h->K + b * ldn * ldm, ldm * 8, m * 8, n, hipMemcpyDeviceToHost));
+        for (int a = 0; a < n; ++a) {
+            K[(size_t)a * m] = tmp[(size_t)a * m + m - 1];
+            memcpy(K + (size_t)a * m + 1, tmp.data() + (size_t)a * m, (size_t)(m - 1) * 8);
+        }
+    }
+    if (e) {
+        tmp.resize(m);
+        HIPCHK(h, hipMemcpy(tmp.data(), h->fv.e + b * ldm, m * 8, hipMemcpyDeviceToHost));
+        e[0] = tmp[m - 1];
+        memcpy(e + 1, tmp.data(), (size_t)(m - 1) * 8);
+    }
     return SLAMK_OK;
 }
 
@@ -1667,9 +1711,9 @@ double slamk_flops_update_stage(int n, int m, int update_form, int stage)
 {
     const int nl = pad16(n), ml = pad16(m);
     double f = 0;
-    if (stage == 0 ? use_fused_solver(nl, ml) : use_fused_joseph(nl, ml)) {
-        // 16^3-tile products (2 * 16^3 flop each)
-        const int MT = ml / 16, NT = nl / 16;
+    if (stage == 0 ? use_fused_solver(nl, m) : use_fused_joseph(nl, m)) {
+        // 16^3-tile products (2 * 16^3 flop each); the altitude row costs no tile when it is taken as a border
+        const int MT = tiled_rows(m) / 16, NT = nl / 16;
         double tp = 0;
         if (stage == 0) {          // fused gain solver: tile Cholesky and the two triangular solves
             for (int j = 0; j < MT; ++j) {

@@ -225,7 +225,8 @@ def test_per_function_parity():
     assert np.array_equal(d["H"] == 0, H == 0)              # same sparsity pattern
     assert helpers.rel_err(d["e"], meas - hmu) < 1e-13
     S = H @ P @ H.T + np.diag(rd)
-    assert helpers.rel_err(np.tril(d["L"]), np.linalg.cholesky(S)) < 1e-12
+    perm = np.r_[1:S.shape[0], 0]                            # the library factors S with the altitude row last
+    assert helpers.rel_err(np.tril(d["L"]), np.linalg.cholesky(S[np.ix_(perm, perm)])) < 1e-12
     assert helpers.rel_err(d["K"], K) < 1e-11
 
 
