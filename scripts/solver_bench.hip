@@ -1,10 +1,14 @@
-// Standalone timing of gain_solver_kernel<11> on 4096 filters (ablation macros select what runs).
+// Standalone timing of gain_solver_kernel<10, true> on 4096 filters (ablation macros select what runs).
 // H is all zero here, so S = R (diagonal): the instruction stream is the same as for real data.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#ifdef STAMPS
+__device__ unsigned long long g_stamps[8][32];
+#define SOLVER_STAMP(i) do { if (blockIdx.x == 2000 && (threadIdx.x & 63) == 0) g_stamps[threadIdx.x >> 6][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #include "../slam_amd/csrc/gain_solver.hip.h"
 using namespace slamk;
 template <typename T> T* dev(const std::vector<T>& h, int B)
@@ -15,28 +19,39 @@ template <typename T> T* dev(const std::vector<T>& h, int B)
 }
 int main()
 {
-    const int B = 4096, MT = 11, NT = 7, ldm = 208, ldn = 112;
+    constexpr int B = 4096, MT = 10, NT = 7, ldm = 208, ldn = 112;
+    constexpr bool BORDER = true;
     const long long sM = (long long)ldm * ldm, sNM = (long long)ldn * ldm;
     std::vector<double> hW((size_t)ldn * ldn), hr(ldm), hz(ldm * 3, 0.0);
-    std::vector<int> hcs(ldm, -1);
+    std::vector<int> hcs(ldm, -1), hm(1, 16 * MT + 1);
     for (int i = 0; i < ldm; ++i) hr[i] = 50.0 + i;
     for (auto& x : hW) x = (double)rand() / RAND_MAX - 0.5;
     FilterView fv;
     memset(&fv, 0, sizeof fv);
     fv.B = B; fv.F = 32; fv.ldn = ldn; fv.ldm = ldm;
     fv.ha = dev(hz, B); fv.hb = dev(hz, B); fv.hcs = dev(hcs, B); fv.rdiag = dev(hr, B);
-    fv.P = dev(hW, B);
+    fv.P = dev(hW, B); fv.m = dev(hm, B);
+    { std::vector<int> st(1, 0); fv.status = dev(st, B); }
     double* K; hipMalloc(&K, sNM * B * 8);
     const size_t lds = (size_t)SolverLds<MT>::TILES * 256 * 8;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gain_solver_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gain_solver_kernel<MT, BORDER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int reps = 3;
     for (int rep = 0; rep < reps; ++rep) {
         hipEventRecord(e0);
-        gain_solver_kernel<MT><<<B, 512, lds>>>(fv, K, nullptr, nullptr, sM, sNM, NT);
+        gain_solver_kernel<MT, BORDER><<<B, 512, lds>>>(fv, K, nullptr, nullptr, sM, sNM, NT);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("%s: %.3f ms\n", VARIANT, ms);
     }
+#ifdef STAMPS
+    unsigned long long hs[8][32];
+    hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_stamps), sizeof hs);
+    for (int w = 0; w < 8; ++w) {
+        printf("wave %d:", w);
+        for (int i = 1; i < 23; ++i) if (hs[w][i]) printf(" [%d]%lld", i, (long long)(hs[w][i] - hs[w][0])); 
+        printf("\n");
+    }
+#endif
     return 0;
 }

@@ -29,6 +29,11 @@
 #include "feature_kernels.hip.h"
 #include "gemm.hip.h"
 
+// Timing builds (scripts/solver_bench.hip) define SOLVER_STAMP(i) to record the cycle counter of one workgroup.
+#ifndef SOLVER_STAMP
+#define SOLVER_STAMP(i)
+#endif
+
 namespace slamk {
 
 __device__ __forceinline__ int tsw(int r, int c) { return r * 16 + (c ^ (r & 14)); }
@@ -117,15 +122,6 @@ __device__ __forceinline__ void inv4(const double* l, const double* id, double* 
     x[8] = -id[3] * (l[8] * x[5]);
 }
 
-// One wavefront: Cholesky of the symmetric 16 x 16 tile t, then t := inv(L) (lower, zero above).
-// xs is a scratch tile; Lg != nullptr receives L (lower, zero above) at Lg[row * ldl + col].
-// Lane (r = lane & 15, cg = lane >> 4) owns A[r][4 cg .. 4 cg + 3] in registers.  The factorisation is
-// right-looking in four steps of four columns: every lane factors the 4 x 4 pivot block itself and solves
-// its own row and the rows of its four columns against it, so one LDS round trip per step is the only
-// communication.  The inverse is formed row by row from the diagonal block leftwards,
-//     X_bc = -(sum_{c < k <= b} X_bk L_kc) inv(L_cc),
-// again one LDS round trip per block column.  No divergent branches: lanes that own nothing in a step
-// keep their values through selects.
 // Two adjacent columns (c0 even) of row r of a tile in one 16-byte LDS access: the XOR of the tile image only
 // touches bits 1..3 of the column, so columns c0 and c0 + 1 stay neighbours.
 __device__ __forceinline__ double2 tile_ld2(const double* t, int r, int c0)
@@ -148,104 +144,87 @@ __device__ __forceinline__ void tile_st4(double* t, int r, int c0, const double*
     tile_st2(t, r, c0 + 2, v[2], v[3]);
 }
 
-__device__ __forceinline__ void diag_tile_factor_invert(double* t, double* xs, double* __restrict__ Lg, int ldl, int lane)
+// g[q] = x of the lane with the same position in 16-lane row q (q = 0..3): an all-gather over the four rows of a
+// wavefront with the row-swap instructions of gfx950 (v_permlane16_swap, v_permlane32_swap), no LDS access.
+__device__ __forceinline__ void rows_allgather(double x, double (&g)[4])
 {
-    const int r = lane & 15, cg = lane >> 4, b = r >> 2, i = r & 3;
-    double cur[4], idall[16];
-    tile_ld4(t, r, 4 * cg, cur);
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);      // [0]: rows 0 0 2 2, [1]: rows 1 1 3 3
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const auto a0 = __builtin_amdgcn_permlane32_swap(a[0], a[0], false, false); // [0]: row 0, [1]: row 2
+    const auto a1 = __builtin_amdgcn_permlane32_swap(a[1], a[1], false, false); // [0]: row 1, [1]: row 3
+    const auto b0 = __builtin_amdgcn_permlane32_swap(b[0], b[0], false, false);
+    const auto b1 = __builtin_amdgcn_permlane32_swap(b[1], b[1], false, false);
+    g[0] = __hiloint2double((int)b0[0], (int)a0[0]);
+    g[1] = __hiloint2double((int)b1[0], (int)a1[0]);
+    g[2] = __hiloint2double((int)b0[1], (int)a0[1]);
+    g[3] = __hiloint2double((int)b1[1], (int)a1[1]);
+}
+
+// x of lane `src` (a constant) in every lane
+__device__ __forceinline__ double lane_bcast(double x, int src)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), src), __builtin_amdgcn_readlane(__double2loint(x), src));
+}
+
+__device__ __forceinline__ double pick4(const double* v, int k)
+{
+    return k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : v[3]));
+}
+
+// One wavefront: Cholesky of the symmetric 16 x 16 tile held in registers in accumulator layout (lane (li, lk),
+// register r: element (lk + 4 r, li)), and inv(L) (lower, zero above) written to the LDS tile t.  Lg != nullptr
+// receives L (lower, zero above) at Lg[row * ldl + col].  Nothing goes through LDS on the way: it is the latency
+// chain of the whole tile Cholesky, and LDS round trips beside seven busy wavefronts were most of its time.
+// Right-looking in four steps of four columns.  Step kb:
+//   - the 4 x 4 pivot block comes to every lane through scalar registers (v_readlane);
+//   - the lane's own row of the pivot columns, A[li][4 kb + q] = A[4 kb + q][li], sits in register kb of the four
+//     lanes (li, q): one all-gather over the 16-lane rows; every lane solves its row against the pivot block,
+//     X = A[li][4 kb ..] inv(L_kk)^T = L[li][4 kb ..];
+//   - the trailing update A -= X X^T is ONE v_mfma_f64_16x16x4_f64 (k = the four columns of the step), operand value
+//     X[li][lk] for both operands;
+//   - the inverse advances beside it on the residual R = I - L_(columns done) X_(rows done):
+//     rows 4 kb .. 4 kb + 3 of inv(L) = inv(L_kk) R[4 kb .., :] (all-gather + 4 x 4 product), then
+//     R -= L[:, 4 kb ..] X_kb, again one MFMA.
+// The two chains (factor, inverse) only share X and interleave.  A pivot that is not positive turns into NaN.
+__device__ __forceinline__ void diag_tile_factor_invert_acc(v4d a, double* __restrict__ t, double* __restrict__ Lg,
+                                                            int ldl, int lane)
+{
+    const int li = lane & 15, lk = lane >> 4;
+    v4d R, out;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) R[r] = (lk + 4 * r == li) ? 1.0 : 0.0;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-        if (kb > 0) tile_st4(t, r, 4 * cg, cur);
-        double d[10], l[10], id[4], ar[4], xr[4];
-        {   // lower triangle of the 4 x 4 pivot block: rows 4 kb .. 4 kb + 3, one or two 16-byte reads each
-            double w[4];
-            d[0] = t[tsw(4 * kb, 4 * kb)];
-            const double2 r1 = tile_ld2(t, 4 * kb + 1, 4 * kb);
-            d[1] = r1.x; d[2] = r1.y;
-            tile_ld4(t, 4 * kb + 2, 4 * kb, w);
-            d[3] = w[0]; d[4] = w[1]; d[5] = w[2];
-            tile_ld4(t, 4 * kb + 3, 4 * kb, w);
-            d[6] = w[0]; d[7] = w[1]; d[8] = w[2]; d[9] = w[3];
-        }
-        tile_ld4(t, r, 4 * kb, ar);
-        double ac[4][4];
+        double d[10], l[10], id[4], g[4], x[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) tile_ld4(t, 4 * cg + p, 4 * kb, ac[p]);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q <= i; ++q) d[i * (i + 1) / 2 + q] = lane_bcast(a[kb], 4 * kb + q + 16 * i);
+        rows_allgather(a[kb], g);
         chol4(d, l, id);
+        solve4(g, l, id, x);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) idall[4 * kb + q] = id[q];
-        solve4(ar, l, id, xr);
+        for (int q = 0; q < 4; ++q) x[q] = (li >= 4 * kb + q) ? x[q] : 0.0;   // L is lower triangular; rows above: done
+        if (Lg && lk == 0) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            double xc[4];
-            solve4(ac[p], l, id, xc);
-            double v = cur[p];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v = fma(-xr[q], xc[q], v);
-            const double own = (r >= 4 * kb + p) ? xr[p] : 0.0;
-            cur[p] = (cg > kb) ? v : ((cg == kb) ? own : cur[p]);
+            for (int q = 0; q < 4; ++q) Lg[(long long)li * ldl + 4 * kb + q] = x[q];
         }
-    }
-    // the factor, zero above the diagonal
-#pragma unroll
-    for (int q = 0; q < 4; ++q) cur[q] = (4 * cg + q <= r) ? cur[q] : 0.0;
-    tile_st4(t, r, 4 * cg, cur);
-    if (Lg) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Lg[(long long)r * ldl + 4 * cg + q] = cur[q];
-    }
-    // inverse of the diagonal block of this lane's column group
-    double lc[10], idc[4], xc[10];
-    {
-        double w[4];
-        lc[0] = t[tsw(4 * cg, 4 * cg)];
-        const double2 r1 = tile_ld2(t, 4 * cg + 1, 4 * cg);
-        lc[1] = r1.x; lc[2] = r1.y;
-        tile_ld4(t, 4 * cg + 2, 4 * cg, w);
-        lc[3] = w[0]; lc[4] = w[1]; lc[5] = w[2];
-        tile_ld4(t, 4 * cg + 3, 4 * cg, w);
-        lc[6] = w[0]; lc[7] = w[1]; lc[8] = w[2]; lc[9] = w[3];
+        const double xo = pick4(x, lk);
+        if (kb < 3) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-xo, xo, a, 0, 0, 0);
+        double iv[10], rr[4], xi[4];
+        inv4(l, id, iv);
+        rows_allgather(R[kb], rr);
+        xi[0] = iv[0] * rr[0];
+        xi[1] = fma(iv[2], rr[1], iv[1] * rr[0]);
+        xi[2] = fma(iv[5], rr[2], fma(iv[4], rr[1], iv[3] * rr[0]));
+        xi[3] = fma(iv[9], rr[3], fma(iv[8], rr[2], fma(iv[7], rr[1], iv[6] * rr[0])));
+        const double xs = pick4(xi, lk);
+        out[kb] = xs;
+        if (kb < 3) R = __builtin_amdgcn_mfma_f64_16x16x4f64(-xo, xs, R, 0, 0, 0);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-        idc[q] = cg == 0 ? idall[q] : (cg == 1 ? idall[4 + q] : (cg == 2 ? idall[8 + q] : idall[12 + q]));
-    inv4(lc, idc, xc);
-    double xrow[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const double v = i == 0 ? (q == 0 ? xc[0] : 0.0)
-                       : i == 1 ? (q <= 1 ? xc[1 + q] : 0.0)
-                       : i == 2 ? (q <= 2 ? xc[3 + q] : 0.0) : xc[6 + q];
-        xrow[q] = (cg == b) ? v : 0.0;
-    }
-    tile_st4(xs, r, 4 * cg, xrow);
-#pragma unroll
-    for (int k = 1; k < 4; ++k) {
-        double v[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int a4 = 0; a4 < k; ++a4) {
-            const int ab = (4 * cg + 4 + 4 * a4) & 15;     // only lanes with b - cg == k keep the result
-            double xv[4];
-            tile_ld4(xs, r, ab, xv);
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                double tr[4];
-                tile_ld4(t, ab + a, 4 * cg, tr);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = fma(xv[a], tr[c], v[c]);
-            }
-        }
-        const bool act = (b - cg == k);
-        double o[4];
-        o[0] = -fma(v[3], xc[6], fma(v[2], xc[3], fma(v[1], xc[1], v[0] * xc[0])));
-        o[1] = -fma(v[3], xc[7], fma(v[2], xc[4], v[1] * xc[2]));
-        o[2] = -fma(v[3], xc[8], v[2] * xc[5]);
-        o[3] = -(v[3] * xc[9]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) xrow[q] = act ? o[q] : xrow[q];
-        tile_st4(xs, r, 4 * cg, xrow);
-    }
-    tile_st4(t, r, 4 * cg, xrow);
+    for (int r = 0; r < 4; ++r) t[tsw(lk + 4 * r, li)] = out[r];
 }
 
 // Tile Cholesky of the MT x MT lower tiles in LDS (tile (i, j) at tile_index(i, j)) together with the forward
@@ -317,16 +296,28 @@ __device__ __forceinline__ void tile_cholesky_forward(double* lds, v4d (&y)[MT],
 
     if (wave == 0) {
         prologue(std::false_type{});
-        diag_tile_factor_invert(lds, lds + NTILES * 256, Lb, ldl, lane);
+        SOLVER_STAMP(1);
+        {
+            v4d a0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a0[r] = lds[tsw(lk + 4 * r, li)];
+            diag_tile_factor_invert_acc(a0, lds, Lb, ldl, lane);
+        }
         for (int j = 0; j < MT; ++j) {
             __syncthreads();                             // A
             if (j + 1 < MT) panel_tile(j + 1, j);
             __syncthreads();                             // B
-            if (j + 1 < MT) {
-                trail(j + 1, j + 1, j);
-                diag_tile_factor_invert(lds + tile_index(j + 1, j + 1) * 256, lds + NTILES * 256,
-                                        Lb ? Lb + (long long)(16 * (j + 1)) * ldl + 16 * (j + 1) : nullptr, ldl, lane);
+            if (j + 1 < MT) {                            // S_j+1,j+1 -= L_j+1,j L_j+1,j^T stays in registers
+                double* tjj = lds + tile_index(j + 1, j + 1) * 256;
+                const double* tp = lds + tile_index(j + 1, j) * 256;
+                v4d acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = tjj[tsw(lk + 4 * r, li)];
+                acc = tile_mma_ldsBt<true>(tp, tp, acc, li, lk);
+                diag_tile_factor_invert_acc(acc, tjj, Lb ? Lb + (long long)(16 * (j + 1)) * ldl + 16 * (j + 1) : nullptr,
+                                            ldl, lane);
             }
+            SOLVER_STAMP(2 + j);
         }
         __syncthreads();
         if (has_blk) {                                   // an eighth block: its forward solve runs here
@@ -335,8 +326,9 @@ __device__ __forceinline__ void tile_cholesky_forward(double* lds, v4d (&y)[MT],
         }
     } else {
         prologue(std::true_type{});
-        // Wavefront 4 shares its SIMD with wavefront 0: it stays out of the factorisation loop, where that SIMD
-        // belongs to the diagonal-tile chain, and runs its forward solve afterwards, when wavefront 0 is idle.
+        SOLVER_STAMP(1);
+        // Wavefront 4 shares its SIMD with wavefront 0, which runs the diagonal-tile chain: it takes no panel or
+        // trailing tiles.
         const int wk6 = wave < 4 ? wave - 1 : wave - 2;  // 0..5 for wavefronts 1 2 3 5 6 7
         const bool worker = wave != 4;
 #pragma unroll
@@ -356,12 +348,12 @@ __device__ __forceinline__ void tile_cholesky_forward(double* lds, v4d (&y)[MT],
                 }
                 if (has_blk) y[j] = forward_step(j, y[j]);
             }
+            // wavefront 4 only advances its forward solve: measured faster inside the loop, beside the chain of
+            // wavefront 0 on the same SIMD, than after it with the other wavefronts idle (1.325 -> 1.277 ms)
+            if (!worker && has_blk) y[j] = forward_step(j, y[j]);
+            SOLVER_STAMP(2 + j);
         }
         __syncthreads();
-        if (!worker && has_blk) {
-#pragma unroll
-            for (int j = 0; j < MT; ++j) y[j] = forward_step(j, y[j]);
-        }
     }
 }
 
@@ -452,6 +444,7 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
         for (int t = tid; t < M; t += 512) { crd[t] = rd[t]; ccs[t] = fv.hcs[rb + t]; }
     }
     __syncthreads();
+    SOLVER_STAMP(0);
     v4d y[MT];
     double* Kpark = K + (long long)b * sNM + (long long)(16 * blk) * ldm;
     auto build = [&](auto with_y) {
@@ -531,6 +524,7 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
         return t;
     });
     if (Lb) store_offdiag_tiles<MT>(lds, Lb, ldm, wave, lane);
+    SOLVER_STAMP(20);
 
     // ---- the altitude row as a border of the factored block -----------------------------------------------
     double k_alt = 0.0;                                  // K[16 blk + li][M], the same in the four lane groups
@@ -574,6 +568,7 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
         }
     }
 
+    SOLVER_STAMP(21);
     // ---- K^T_j = inv(L_jj)^T (Y^T_j - sum_{k>j} L_kj^T K^T_k),  j = MT-1 .. 0 -----------------------------
     if (!has_blk) return;
     if (border && lk == 0) {                             // the altitude column of K
@@ -606,6 +601,7 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
         }
     }
     if (!(mag < 1.0e300)) atomicOr(fv.status + b, 2);    // S was not positive definite
+    SOLVER_STAMP(22);
 }
 
 // Diagonal block of the blocked Cholesky of a large S: factor the 16 MT x 16 MT block at (j0, j0) (lower part
