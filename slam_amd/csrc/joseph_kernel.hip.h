@@ -27,6 +27,9 @@
 
 #include "gain_solver.hip.h"
 
+#ifndef JOSEPH_STAMP
+#define JOSEPH_STAMP(i)    // timing builds (scripts/joseph_bench.hip) record the cycle counter of one workgroup here
+#endif
 #ifndef JOSEPH_STOP
 #define JOSEPH_STOP 0      // > 0: timing builds that leave the kernel after a phase
 #endif
@@ -81,45 +84,54 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
     const int ia = fv.m[b] - 1;                         // altitude row of H / column of K
     const bool border = (ia == mlc);                    // not covered by the chunk loop
 
-    // P tiles of this wavefront go to registers first: their latency hides behind phase A
+    JOSEPH_STAMP(0);
+    // The P tiles of this wavefront go to registers during phase A, one tile per pass over the rows of K and behind
+    // that pass's request for the next rows of K: vector memory loads complete in order, so whatever a pass waits for
+    // must not sit behind more tile loads than one pass can cover (all 28 at the start held up the first barrier, all
+    // of them behind the first rows of K held up the second pass).
     constexpr int PT = (NT * NT + 7) / 8;
+    static_assert(PT <= NT, "one P tile per pass");
     double pre_p[PT][4];
-#pragma unroll
-    for (int u = 0; u < PT; ++u) {
+    auto request_p = [&](int u) {
         const int t = wave + 8 * u;
         const int I = t / NT, J = t - I * NT;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             pre_p[u][r] = (t < NT * NT) ? Pb[(long long)(16 * I + lk + 4 * r) * ldn + 16 * J + li] : 0.0;
-    }
+    };
 
     // ---- phase A: A = I - K H in LDS -------------------------------------------------------------------
-    for (int t = tid; t < NT * NT * 256; t += 512) lds[t] = 0.0;
-    for (int t = tid; t < mlc; t += 512) rds[t] = fv.rdiag[(long long)b * fv.ldm + t];
     // The altitude row (H row ia = (ha, 0), main.cpp:354) is taken by one thread per row j of A, ahead of the
     // feature rows: A[j][0..2] = I - K[j][ia] ha, and its share of dx_j = sum_q K[j][q] e[q] (main.cpp:228).
-    double ka_own = 0.0;
+    double ka_own = 0.0, e_alt = 0.0, hal[3] = {0.0, 0.0, 0.0};
     if (tid < 16 * NT) {
         ka_own = Kb[(long long)tid * ldk + ia];
+        e_alt = fv.e[(long long)b * fv.ldm + ia];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) hal[c] = fv.ha[((long long)b * fv.ldm + ia) * 3 + c];
+    }
+    for (int t = tid; t < mlc; t += 512) rds[t] = fv.rdiag[(long long)b * fv.ldm + t];
+    for (int t = tid; t < NT * NT * 256; t += 512) lds[t] = 0.0;
+    if (tid < 16 * NT) {
         kalt[tid] = ka_own;
-        dxs[tid] = ka_own * fv.e[(long long)b * fv.ldm + ia];
+        dxs[tid] = ka_own * e_alt;
     }
     __syncthreads();
     if (tid < 16 * NT) {
         lds[((tid >> 4) * (NT + 1)) * 256 + tsw(tid & 15, tid & 15)] = 1.0;
-        const double* hal = fv.ha + ((long long)b * fv.ldm + ia) * 3;
         double* row = lds + ((tid >> 4) * NT) * 256;
 #pragma unroll
         for (int c = 0; c < 3; ++c) row[tsw(tid & 15, c)] = (tid == c ? 1.0 : 0.0) - ka_own * hal[c];
     }
     __syncthreads();
+    JOSEPH_STAMP(1);
     {
         const double* hb = fv.hb + (long long)b * fv.ldm * 3;
         const double* ha = fv.ha + (long long)b * fv.ldm * 3;
         const int half = lane >> 5, l32 = lane & 31;
         // lane = feature i: columns 6 + 3 i .. + 2 from its 4 or 6 measurement rows, and its share of the
         // position columns 0..2 (summed over the lanes)
-        for (int i0 = 0; i0 < nf; i0 += 32) {
+        auto feature_block = [&](int i0, auto first) {      // 32 features; the first block also requests the P tiles
             const int i = i0 + l32;
             const bool live = i < nf;
             const int row0 = live ? fv.rowoff[(long long)b * fv.F + i] : 0;
@@ -136,22 +148,28 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
 #pragma unroll
             for (int t = 0; t < 6; ++t) ef[t] = (live && (t < 4 || six)) ? ev[row0 + t] : 0.0;
             const int l0 = 6 + 3 * i;
-            // the gain entries of the next pass are requested before this pass is worked on
-            double kn[6];
+            // The gain entries are requested KDEPTH passes ahead (a pass waits for a round trip to memory otherwise);
+            // a feature's 4 or 6 entries of a row of K are a 16-byte aligned run (row offsets and ldk are even).
+            constexpr int KDEPTH = (NT <= 7) ? 2 : 1;       // (no registers to spare for two at NT = 8)
+            double2 kn[KDEPTH][3];
             auto fetch = [&](int pass) {
-                const double* kr = Kb + (long long)(pass * 16 + wave * 2 + half) * ldk;
+                const double2* kr = reinterpret_cast<const double2*>(Kb + (long long)(pass * 16 + wave * 2 + half) * ldk + row0);
 #pragma unroll
-                for (int t = 0; t < 6; ++t) kn[t] = (live && (t < 4 || six)) ? kr[row0 + t] : 0.0;
+                for (int t = 0; t < 3; ++t)
+                    kn[pass % KDEPTH][t] = (live && (t < 2 || six)) ? kr[t] : make_double2(0.0, 0.0);
             };
-            fetch(0);
+#pragma unroll
+            for (int pass = 0; pass < KDEPTH && pass < NT; ++pass) fetch(pass);
 #pragma unroll
             for (int pass = 0; pass < NT; ++pass) {
                 const int j = pass * 16 + wave * 2 + half;
-                if (pass > 0 && NT > 7) fetch(pass);
                 double k[6];
 #pragma unroll
-                for (int t = 0; t < 6; ++t) k[t] = kn[t];
-                if (pass + 1 < NT && NT <= 7) fetch(pass + 1);      // (no registers to spare for it at NT = 8)
+                for (int t = 0; t < 3; ++t) { k[2 * t] = kn[pass % KDEPTH][t].x; k[2 * t + 1] = kn[pass % KDEPTH][t].y; }
+                if (pass + KDEPTH < NT) fetch(pass + KDEPTH);
+                if constexpr (decltype(first)::value) {
+                    if (pass < PT) request_p(pass);
+                }
                 double x[3] = {0.0, 0.0, 0.0};
                 double de = 0.0;                         // this lane's share of dx_j = sum_q K[j][q] e[q]   (main.cpp:228)
 #pragma unroll
@@ -172,9 +190,12 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
                 if (l32 == 3) dxs[j] += sde;
                 if (l32 < 3) lds[((j >> 4) * NT) * 256 + tsw(j & 15, l32)] -= (l32 == 0 ? sx0 : (l32 == 1 ? sx1 : sx2));
             }
-        }
+        };
+        feature_block(0, std::true_type{});                 // also without features: the P tiles are requested here
+        for (int i0 = 32; i0 < nf; i0 += 32) feature_block(i0, std::false_type{});
     }
     __syncthreads();
+    JOSEPH_STAMP(2);
     if (dx && tid < 16 * NT) dx[(long long)b * ldn + tid] = dxs[tid];
     double af[4 * NT];
     if (active) {
@@ -221,6 +242,7 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
             }
         }
     }
+    JOSEPH_STAMP(3);
     // ---- phase 1: AP(blk, :) = A(blk, :) P -------------------------------------------------------------
     v4d acc[NT];
     if (active) {
@@ -259,6 +281,7 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
         return;
     }
 
+    JOSEPH_STAMP(4);
     // ---- phase 2: column J = blk of the lower triangle ---------------------------------------------------
     const int J = blk;
     v4d o[NT];
@@ -284,27 +307,35 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
 #if JOSEPH_STOP == 4
     { double z = 0; for (int t = 0; t < NT; ++t) z += o[t][0] + o[t][1] + o[t][2] + o[t][3]; if (form == 99) Pb[tid] = z; return; }
 #endif
+    JOSEPH_STAMP(5);
     {
         // K R K^T: wavefront w < NT stages tile (w, chunk) of K; the next chunk is in flight during the products
         const double* ksrc = Kb + (long long)(16 * wave + lk) * ldk + li;     // element (lk + 4 r, li) of tile `wave`
         const long long r4 = (long long)4 * ldk;
         const bool loader = wave < NT;
-        double pre[4] = {0, 0, 0, 0};
+        // the chunks are requested two ahead: one chunk of products does not cover a round trip to memory
+        const int nchunk = mlc / 16;
+        double pre[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
         if (loader) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pre[r] = ksrc[r * r4];
+            for (int r = 0; r < 4; ++r) pre[0][r] = ksrc[r * r4];
+            if (nchunk > 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pre[1][r] = ksrc[r * r4 + 16];
+            }
         }
-        const int nchunk = mlc / 16;
         for (int c = 0; c < nchunk; ++c) {
             double* kc = kst + (KBUF == 2 ? (c & 1) * NT * 256 : 0);
             if (loader) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) kc[wave * 256 + tsw(lk + 4 * r, li)] = pre[r];
+                for (int r = 0; r < 4; ++r) kc[wave * 256 + tsw(lk + 4 * r, li)] = pre[0][r];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pre[0][r] = pre[1][r];
             }
             __syncthreads();
-            if (loader && c + 1 < nchunk) {
+            if (loader && c + 2 < nchunk) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pre[r] = ksrc[r * r4 + 16 * (c + 1)];
+                for (int r = 0; r < 4; ++r) pre[1][r] = ksrc[r * r4 + 16 * (c + 2)];
             }
             if (active) {
                 // all operand fragments of the chunk are requested before the first product: one LDS latency per
@@ -345,6 +376,7 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
 #if JOSEPH_STOP == 5
     { double z = 0; for (int t = 0; t < NT; ++t) z += o[t][0] + o[t][1] + o[t][2] + o[t][3]; if (form == 99) Pb[tid] = z; return; }
 #endif
+    JOSEPH_STAMP(6);
     if (!active) return;
     // Every tile goes out twice: as it is (rows of 128 bytes), and mirrored.  The mirror image is read back
     // transposed from a tile of LDS (the AP tiles are dead by now; wavefront w uses tile w) so that its stores are
@@ -368,6 +400,7 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
             if (16 * I + a > 16 * J + bq) Pb[(long long)(16 * J + bq) * ldn + 16 * I + a] = v;
         }
     }
+    JOSEPH_STAMP(7);
 }
 
 }  // namespace slamk
