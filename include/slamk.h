@@ -113,6 +113,15 @@ int slamk_num_rows(slamk_handle* h, int b);
  * measurement of the next slamk_update for this filter.  b = -1 applies the same frame to every
  * filter of the batch (they must hold the same ids). */
 int slamk_frame(slamk_handle* h, int b, const slamk_match* matches, int nmatch, const double quat[4]);
+/* The frames of ALL filters of the batch in one call (same reference code as slamk_frame), ordered on `stream` and
+ * without host synchronisation: the association is planned on the host, uploaded in one copy and applied by a fixed
+ * number of launches, whatever the batch.  match_off == NULL: the nmatch entries of `matches` are the frame of every
+ * filter and quat holds 4 doubles.  Otherwise filter b's frame is matches[match_off[b] .. match_off[b + 1]) (nmatch
+ * is ignored; an empty range is a frame without features) and quat holds [batch][4].  matches, match_off and quat
+ * are HOST memory and may be reused as soon as the call returns.  When a frame does not fit (SLAMK_ECAPACITY)
+ * nothing has been queued for any filter. */
+int slamk_frame_batch_async(slamk_handle* h, const slamk_match* matches, int nmatch, const int32_t* match_off,
+                            const double* quat, void* stream);
 /* Replaces only the observation values (not ids / reflection presence) of the frame kept for
  * filter b: src2/refl2 are [nf][2] in slot order.  For Monte-Carlo batches that share one
  * association but carry independent pixel noise. */

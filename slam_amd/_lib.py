@@ -40,6 +40,7 @@ SIGNATURES = {
     "slamk_num_features": (C.c_int, [_H, C.c_int]),
     "slamk_num_rows": (C.c_int, [_H, C.c_int]),
     "slamk_frame": (C.c_int, [_H, C.c_int, C.POINTER(Match), C.c_int, _vp]),
+    "slamk_frame_batch_async": (C.c_int, [_H, C.POINTER(Match), C.c_int, _vp, _vp, _vp]),
     "slamk_set_frame_values": (C.c_int, [_H, C.c_int, _vp, _vp]),
     "slamk_predict": (C.c_int, [_H, _vp, _vp, _vp, _vp]),
     "slamk_update": (C.c_int, [_H, _vp, _vp, _vp]),

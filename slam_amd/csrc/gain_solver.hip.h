@@ -329,18 +329,30 @@ __device__ __forceinline__ void tile_cholesky_forward(double* lds, v4d (&y)[MT],
         SOLVER_STAMP(1);
         // Wavefront 4 shares its SIMD with wavefront 0, which runs the diagonal-tile chain: it takes no panel or
         // trailing tiles.
-        const int wk6 = wave < 4 ? wave - 1 : wave - 2;  // 0..5 for wavefronts 1 2 3 5 6 7
+        const int wk6 = wave < 4 ? wave - 1 : (wave == 4 ? 6 : wave - 2);  // 0..5 for wavefronts 1 2 3 5 6 7, 6 for 4
         const bool worker = wave != 4;
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
+            // On the first columns the other wavefronts' trailing tiles, not the chain of wavefront 0, set the pace:
+            // wavefront 4 joins them there.
+            const int nw = (2 * j + 4 < MT) ? 7 : 6;
             __syncthreads();                             // A
             if (worker)
                 for (int i = j + 2 + wk6; i < MT; i += 6) panel_tile(i, j);
             __syncthreads();                             // B
+            if (!worker && nw == 7) {
+                const int w = MT - j - 2;
+                for (int t = 6; t < w * (w + 1) / 2; t += 7) {
+                    int ii = 0;
+                    while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+                    const int kk = t - ii * (ii + 1) / 2;
+                    trail(j + 2 + ii, j + 2 + kk, j);
+                }
+            }
             if (worker) {
                 for (int i = j + 2 + wk6; i < MT; i += 6) trail(i, j + 1, j);      // column j + 1 first
                 const int w = MT - j - 2;
-                for (int t = wk6; t < w * (w + 1) / 2; t += 6) {
+                for (int t = wk6; t < w * (w + 1) / 2; t += nw) {
                     int ii = 0;
                     while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
                     const int kk = t - ii * (ii + 1) / 2;
@@ -431,6 +443,12 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
     // instead of three in a row at the start of the workgroup.
     const int ec = tid & 15, ea = tid >> 4;              // panel column, row within a group of 32 rows
     double px[4][3], pf[4][3];                           // P[a][0..2] once, P[a][cs..cs+2] per panel
+    // what the border step needs from memory is requested here, a whole factorisation ahead of its use
+    double w_alt = 0.0, sigma_alt = 0.0;
+    if constexpr (BORDER) {
+        w_alt = has_blk ? -Pb[(long long)min(16 * blk + li, nl - 1) * ldn + 2] : 0.0;
+        sigma_alt = Pb[2 * ldn + 2] + rd[M];
+    }
     {
         const long long rb = (long long)b * ldm;
         const int cs0 = max(fv.hcs[rb + ec], 0);
@@ -533,8 +551,7 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
         border = (fv.m[b] - 1 == M);                     // uniform over the workgroup
         if (border) {
             double* lvec = scratch;                      // [M]: l; the diagonal-tile scratch tile is free by now
-            const double w_a = has_blk ? -Pb[(long long)min(16 * blk + li, nl - 1) * ldn + 2] : 0.0;
-            const double sigma = Pb[2 * ldn + 2] + rd[M];
+            const double w_a = w_alt, sigma = sigma_alt;
             if (blk == 0 && li == 2) {                   // row 2 of Y_f: lane = column 2 of the wavefront's Y^T tiles
 #pragma unroll
                 for (int j = 0; j < MT; ++j)

@@ -39,39 +39,6 @@ __global__ void __launch_bounds__(256) copy_block_kernel(const double* __restric
     if (i < rows && j < cols) dst[off + (long long)i * ld + j] = src[off + (long long)i * ld + j];
 }
 
-// Covariance surgery as one gather (States::update_features, src/ARC/states.cpp:129-139,
-// 141-166, 179-196): out[i][j] = P[src[i]][src[j]] when both sources exist, p0 on the diagonal of
-// a fresh row, 0 elsewhere.  src has nl entries; -1 = fresh (new feature), -2 = padding.
-// One matrix of the batch per blockIdx.z (batch stride `stride` on both sides); the map is shared.
-__global__ void __launch_bounds__(256) remap_cov_kernel(const double* __restrict__ P, double* __restrict__ out,
-                                                         const int* __restrict__ src, int ld, long long stride, int nl,
-                                                         double p0)
-{
-    const long long off = (long long)blockIdx.z * stride;
-    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (i >= nl || j >= nl) return;
-    const int si = src[i], sj = src[j];
-    double v = 0.0;
-    if (si >= 0 && sj >= 0) v = P[off + (long long)si * ld + sj];
-    else if (i == j && si == -1) v = p0;
-    out[off + (long long)i * ld + j] = v;
-}
-
-// Per-feature container gather for the same surgery: dst slot i takes src slot map[i] (>= 0) or is
-// left for the initialiser (-1).  ncomp components, arrays are [ncomp][F] per filter; one filter per
-// blockIdx.y, the map is shared.
-__global__ void gather_slots_kernel(const double* __restrict__ src, double* __restrict__ dst,
-                                    const int* __restrict__ map, int F, int nf_new, int ncomp)
-{
-    const long long off = (long long)blockIdx.y * ncomp * F;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nf_new) return;
-    const int s = map[i];
-    if (s < 0) return;
-    for (int c = 0; c < ncomp; ++c) dst[off + (long long)c * F + i] = src[off + (long long)c * F + s];
-}
-
 // MFMA issue-rate probe: every wave runs `iters` rounds of 8 independent accumulators.
 __global__ void __launch_bounds__(256) mfma_probe_kernel(double* out, int iters)
 {

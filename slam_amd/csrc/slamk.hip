@@ -22,6 +22,7 @@
 #include "structured_kernels.hip.h"
 #include "joseph_kernel.hip.h"
 #include "preprocess_kernels.hip.h"
+#include "frame_kernels.hip.h"
 
 using namespace slamk;
 
@@ -63,10 +64,12 @@ struct slamk_handle {
     // staging
     double *qbw_d = nullptr, *w_d = nullptr, *acc_d = nullptr, *dt_d = nullptr, *alt_d = nullptr;
     int *applied_d = nullptr;
-    int *map_d = nullptr;                 // [ldn] index map for surgery
-    double *feat_tmp = nullptr;           // [B][4][F] scratch for slot gathers
-    int *slots_d = nullptr;               // [F] slots of new features
-    double *sxy_d = nullptr;              // [F][2] their first observations
+    double *feat_tmp = nullptr;           // [B][12][F] copy of the per-feature containers while slots move
+    // image frames: one pinned staging block and its device mirror per handle (apply_frames)
+    void *stage_host = nullptr, *stage_dev = nullptr;
+    size_t stage_bytes = 0;
+    hipEvent_t stage_copied = nullptr;
+    bool stage_in_flight = false;
     std::vector<void*> allocs;
     int have_ws = 0;                      // WS_* groups allocated so far (ensure_workspaces)
     std::string err;
@@ -333,23 +336,6 @@ int push_layout(slamk_handle* h, int b0, int cnt)
     HIPCHK(h, hipMemcpy(h->fv.isref + (size_t)b0 * F, isr.data(), isr.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->fv.rowoff + (size_t)b0 * F, ro.data(), ro.size() * sizeof(int), hipMemcpyHostToDevice));
     return 0;
-}
-
-__global__ void init_features_kernel(FilterView fv, int count, const int* __restrict__ slots,
-                                     const double* __restrict__ sxy, double q1, double q2, double q3, double q4,
-                                     double inv_dinit)
-{
-    const int b = blockIdx.y;                  // filter of the (range) view
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= count) return;
-    const int i = slots[t], F = fv.F;
-    const long long f3 = (long long)b * 3 * F, f4 = (long long)b * 4 * F, f2 = (long long)b * 2 * F;
-    const double sx = sxy[2 * t], sy = sxy[2 * t + 1];
-    // Feature::initialize, src/ARC/feature.cpp:61-62,71,87-88
-    fv.pib[f3 + i] = sx; fv.pib[f3 + F + i] = sy; fv.pib[f3 + 2 * F + i] = inv_dinit;
-    for (int c = 0; c < 3; ++c) fv.anchor[f3 + (long long)c * F + i] = fv.X[3 * b + c];
-    fv.q0[f4 + i] = q1; fv.q0[f4 + F + i] = q2; fv.q0[f4 + 2 * F + i] = q3; fv.q0[f4 + 3 * F + i] = q4;
-    fv.pib0[f2 + i] = sx; fv.pib0[f2 + F + i] = sy;
 }
 
 __global__ void init_cov_kernel(double* P, int ld, long long stride, double pinit)
@@ -891,8 +877,7 @@ int slamk_create(const slamk_params* p, int max_features, int batch, int device,
     rc |= dalloc(h, &h->dx, B * ldn);
     rc |= dalloc(h, &h->qbw_d, B * 4); rc |= dalloc(h, &h->w_d, B * 3); rc |= dalloc(h, &h->acc_d, B * 3);
     rc |= dalloc(h, &h->dt_d, B); rc |= dalloc(h, &h->alt_d, B); rc |= dalloc(h, &h->applied_d, B);
-    rc |= dalloc(h, &h->map_d, ldn); rc |= dalloc(h, &h->feat_tmp, B * 4 * F);
-    rc |= dalloc(h, &h->slots_d, F); rc |= dalloc(h, &h->sxy_d, 2 * F);
+    rc |= dalloc(h, &h->feat_tmp, B * FRAME_COMPS * F);
     if (rc) return SLAMK_EHIP;
     v.Q0 = h->prm.Q0; v.R0 = h->prm.R0; v.qbias = h->prm.qbias; v.gate = h->prm.gate;
     v.inv_dmax = 1 / h->prm.d_max; v.inv_dmin = 1 / h->prm.d_min;
@@ -910,6 +895,9 @@ int slamk_destroy(slamk_handle* h)
     DeviceGuard dg_(h->device);
     (void)hipDeviceSynchronize();
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->stage_host) (void)hipHostFree(h->stage_host);
+    if (h->stage_dev) (void)hipFree(h->stage_dev);
+    if (h->stage_copied) (void)hipEventDestroy(h->stage_copied);
     for (auto& g : h->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
     for (auto g : h->gstreams) (void)hipStreamDestroy(g);
     for (auto e : h->gdone) (void)hipEventDestroy(e);
@@ -1072,99 +1060,183 @@ static int plan_frame(slamk_handle* h, const HostFilter& f, const slamk_match* m
     return SLAMK_OK;
 }
 
-// Applies one plan to the filters [b0, b0 + cnt), whose host mirrors are identical: every device step is
-// one launch over the whole range.
-static int apply_frame(slamk_handle* h, int b0, int cnt, const FramePlan& p, const slamk_match* matches, int nmatch,
-                       const double quat[4])
+// One group of filters that take the same plan: the frame's matches and attitude, and the plan.
+struct FrameGroup {
+    FramePlan plan;
+    const slamk_match* matches;
+    int nmatch;
+    const double* quat;
+};
+
+// Applies the plans to the filters [b0, b0 + cnt): grp[c] = group of filter b0 + c.  One upload (from a pinned
+// staging block) and a fixed number of launches on `st`, whatever the number of filters; no host synchronisation
+// unless `sync`.
+static int apply_frames(slamk_handle* h, int b0, int cnt, const std::vector<FrameGroup>& groups, const std::vector<int>& grp,
+                        hipStream_t st, bool sync)
 {
-    const int F = h->F, ldn = h->ldn, nf = p.nf, old_nf = p.old_nf;
+    const size_t F = h->F, ldn = h->ldn, G = groups.size();
+    // staging layout: doubles first (sxy, quat, ms, mr), then ints (grp, nf, m, changed, isref, rowoff, smap, imap)
+    const size_t nd = G * (2 * F + 4 + 2 * F + 2 * F), ni = cnt + 3 * G + 3 * G * F + G * ldn;
+    const size_t bytes = nd * sizeof(double) + ni * sizeof(int);
+    if (h->stage_in_flight) {                     // the previous upload has left the pinned block
+        HIPCHK(h, hipEventSynchronize(h->stage_copied));
+        h->stage_in_flight = false;
+    }
+    if (bytes > h->stage_bytes) {
+        if (h->stage_host) { HIPCHK(h, hipStreamSynchronize(st)); (void)hipHostFree(h->stage_host); (void)hipFree(h->stage_dev); }
+        const size_t cap = std::max(bytes * 2, (size_t)1 << 16);
+        HIPCHK(h, hipHostMalloc(&h->stage_host, cap, hipHostMallocDefault));
+        HIPCHK(h, hipMalloc(&h->stage_dev, cap));
+        h->stage_bytes = cap;
+        if (!h->stage_copied) HIPCHK(h, hipEventCreateWithFlags(&h->stage_copied, hipEventDisableTiming));
+    }
+    double* hd = static_cast<double*>(h->stage_host);
+    int* hi = reinterpret_cast<int*>(hd + nd);
+    memset(h->stage_host, 0, bytes);
+    double *sxy = hd, *quat = sxy + G * 2 * F, *ms = quat + G * 4, *mr = ms + G * 2 * F;
+    int *gr = hi, *nfv = gr + cnt, *mv = nfv + G, *chg = mv + G, *isr = chg + G, *ro = isr + G * F, *smap = ro + G * F,
+        *imap = smap + G * F;
+    bool any_changed = false;
+    int nl = 16, nf_hi = 0;
+    for (size_t g = 0; g < G; ++g) {
+        const FramePlan& p = groups[g].plan;
+        nfv[g] = p.nf;
+        int row = 0;
+        for (int i = 0; i < p.nf; ++i) {
+            isr[g * F + i] = p.nisr[i];
+            ro[g * F + i] = row;
+            row += p.nisr[i] ? 6 : 4;
+            smap[g * F + i] = p.nsrc[i];
+            // the frame's observation of the feature in slot i (the id search of measurementModel, main.cpp:362-375)
+            const slamk_match* mt = nullptr;
+            if (p.nfresh[i] >= 0) mt = &groups[g].matches[p.nfresh[i]];
+            else
+                for (int k = 0; k < groups[g].nmatch; ++k)
+                    if (groups[g].matches[k].id == p.nid[i]) { mt = &groups[g].matches[k]; break; }
+            if (!mt) return fail(h, SLAMK_ENOMATCH, "Cannot find match.");
+            ms[g * 2 * F + i] = mt->sx; ms[g * 2 * F + F + i] = mt->sy;
+            mr[g * 2 * F + i] = mt->rx; mr[g * 2 * F + F + i] = mt->ry;
+            if (p.nfresh[i] >= 0) { sxy[g * 2 * F + i] = mt->sx; sxy[g * 2 * F + F + i] = mt->sy; }
+        }
+        mv[g] = row + 1;                           // feature rows first, the altitude row last
+        for (int c = 0; c < 4; ++c) quat[4 * g + c] = groups[g].quat[c];
+        chg[g] = p.identity ? 0 : 1;
+        int* im = imap + g * ldn;
+        for (size_t r = 0; r < ldn; ++r) im[r] = -2;
+        for (int c = 0; c < 6; ++c) im[c] = c;
+        for (int i = 0; i < p.nf; ++i)
+            for (int c = 0; c < 3; ++c) im[6 + 3 * i + c] = p.nsrc[i] >= 0 ? 6 + 3 * p.nsrc[i] + c : -1;
+        for (int c = 0; c < 3; ++c) im[6 + 3 * p.nf + c] = 6 + 3 * p.old_nf + c;
+        if (!p.identity) {
+            any_changed = true;
+            nl = std::max(nl, pad16(9 + 3 * std::max(p.nf, p.old_nf)));
+        }
+        nf_hi = std::max(nf_hi, p.nf);
+    }
+    for (int c = 0; c < cnt; ++c) gr[c] = grp[c];
+
+    HIPCHK(h, hipMemcpyAsync(h->stage_dev, h->stage_host, bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipEventRecord(h->stage_copied, st));
+    h->stage_in_flight = true;
+    const double* dd = static_cast<const double*>(h->stage_dev);
+    const int* di = reinterpret_cast<const int*>(dd + nd);
+    FrameStage fs;
+    fs.sxy = dd; fs.quat = dd + G * 2 * F; fs.ms = fs.quat + G * 4; fs.mr = fs.ms + G * 2 * F;
+    fs.grp = di; fs.nf = di + cnt; fs.m = fs.nf + G; fs.changed = fs.m + G; fs.isref = fs.changed + G;
+    fs.rowoff = fs.isref + G * F; fs.smap = fs.rowoff + G * F; fs.imap = fs.smap + G * F;
+
     const Range rg = make_range(h, b0, cnt);
-    // old_pos = X, depth clamp (main.cpp:168, states.cpp:91-103)
-    hipLaunchKernelGGL(frame_begin_kernel, dim3(cnt), dim3(256), 0, 0, rg.fv, -1);
-    if (!p.identity) {
-        // per-feature containers: copy out, gather back
-        struct Arr { double* q; int nc; } arrs[4] = {{rg.fv.pib, 3}, {rg.fv.anchor, 3}, {rg.fv.q0, 4}, {rg.fv.pib0, 2}};
-        std::vector<int> smap(std::max(1, nf));
-        for (int i = 0; i < nf; ++i) smap[i] = p.nsrc[i];
-        HIPCHK(h, hipMemcpy(h->map_d, smap.data(), smap.size() * sizeof(int), hipMemcpyHostToDevice));
-        for (auto& a : arrs) {
-            HIPCHK(h, hipMemcpyAsync(h->feat_tmp, a.q, (size_t)cnt * a.nc * F * sizeof(double), hipMemcpyDeviceToDevice, 0));
-            if (nf) hipLaunchKernelGGL(gather_slots_kernel, dim3((nf + 255) / 256, cnt), dim3(256), 0, 0, h->feat_tmp, a.q,
-                                       h->map_d, F, nf, a.nc);
-        }
-        // covariance rows/cols: one gather through the state-index map
-        const int n_new = 9 + 3 * nf, nl = pad16(std::max(n_new, 9 + 3 * old_nf));
-        std::vector<int> imap(ldn, -2);
-        for (int c = 0; c < 6; ++c) imap[c] = c;
-        for (int i = 0; i < nf; ++i)
-            for (int c = 0; c < 3; ++c) imap[6 + 3 * i + c] = p.nsrc[i] >= 0 ? 6 + 3 * p.nsrc[i] + c : -1;
-        for (int c = 0; c < 3; ++c) imap[6 + 3 * nf + c] = 6 + 3 * old_nf + c;
-        HIPCHK(h, hipMemcpy(h->map_d, imap.data(), ldn * sizeof(int), hipMemcpyHostToDevice));
-        const long long sN = (long long)ldn * ldn;
-        hipLaunchKernelGGL(remap_cov_kernel, dim3((nl + 63) / 64, (nl + 3) / 4, cnt), dim3(256), 0, 0, rg.fv.P, rg.T,
-                           h->map_d, ldn, sN, nl, h->prm.p0);
-        hipLaunchKernelGGL(copy_block_kernel, dim3((nl + 63) / 64, (nl + 3) / 4, cnt), dim3(256), 0, 0, rg.T, rg.fv.P, ldn,
-                           sN, nl, nl);
+    double* tmp = h->feat_tmp + (size_t)b0 * FRAME_COMPS * F;
+    const dim3 fgrid((unsigned)((F + 255) / 256), (unsigned)cnt);
+    // old_pos = X, depth clamp (main.cpp:168, states.cpp:91-103): before any slot moves
+    hipLaunchKernelGGL(frame_begin_kernel, dim3(cnt), dim3(256), 0, st, rg.fv, -1);
+    if (any_changed) hipLaunchKernelGGL(frame_stash_kernel, fgrid, dim3(256), 0, st, rg.fv, fs, tmp);
+    hipLaunchKernelGGL(frame_gather_kernel, fgrid, dim3(256), 0, st, rg.fv, fs, tmp, 1 / h->prm.dinit);
+    if (any_changed) {
+        const dim3 cgrid((nl + 63) / 64, (nl + 3) / 4, cnt);
+        hipLaunchKernelGGL(frame_remap_cov_kernel<false>, cgrid, dim3(256), 0, st, rg.fv, fs, rg.fv.P, rg.T, nl, h->prm.p0);
+        hipLaunchKernelGGL(frame_remap_cov_kernel<true>, cgrid, dim3(256), 0, st, rg.fv, fs, rg.fv.P, rg.T, nl, h->prm.p0);
     }
+    HIPCHK(h, hipGetLastError());
     for (int c = 0; c < cnt; ++c) {
+        const FramePlan& p = groups[grp[c]].plan;
         HostFilter& f = h->hf[b0 + c];
-        f.nf = nf; f.id = p.nid; f.isref = p.nisr;
+        f.nf = p.nf; f.id = p.nid; f.isref = p.nisr;
     }
-    int rc = push_layout(h, b0, cnt);
-    if (rc) return rc;
-    // new features: Feature(X, sense, match)  feature.cpp:41-91
-    std::vector<int> slots; std::vector<double> sxy;
-    for (int i = 0; i < nf; ++i)
-        if (p.nfresh[i] >= 0) {
-            slots.push_back(i); sxy.push_back(matches[p.nfresh[i]].sx); sxy.push_back(matches[p.nfresh[i]].sy);
-        }
-    if (!slots.empty()) {
-        HIPCHK(h, hipMemcpy(h->slots_d, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(h, hipMemcpy(h->sxy_d, sxy.data(), sxy.size() * sizeof(double), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(init_features_kernel, dim3(((int)slots.size() + 63) / 64, cnt), dim3(64), 0, 0, rg.fv,
-                           (int)slots.size(), h->slots_d, h->sxy_d, quat[0], quat[1], quat[2], quat[3], 1 / h->prm.dinit);
-    }
-    // keep the frame's observations in slot order (the id search of measurementModel, main.cpp:362-375)
-    std::vector<double> ms((size_t)cnt * 2 * F, 0.0), mr((size_t)cnt * 2 * F, 0.0);
-    for (int i = 0; i < nf; ++i) {
-        const slamk_match* mt = nullptr;
-        for (int k = 0; k < nmatch; ++k)
-            if (matches[k].id == p.nid[i]) { mt = &matches[k]; break; }
-        if (!mt) return fail(h, SLAMK_ENOMATCH, "Cannot find match.");
-        ms[i] = mt->sx; ms[F + i] = mt->sy;
-        mr[i] = mt->rx; mr[F + i] = mt->ry;
-    }
-    for (int c = 1; c < cnt; ++c) {
-        std::copy(ms.begin(), ms.begin() + 2 * F, ms.begin() + (size_t)c * 2 * F);
-        std::copy(mr.begin(), mr.begin() + 2 * F, mr.begin() + (size_t)c * 2 * F);
-    }
-    HIPCHK(h, hipMemcpy(rg.fv.msrc, ms.data(), ms.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(rg.fv.mrefl, mr.data(), mr.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(h, hipDeviceSynchronize());
     h->mark_begun(b0, cnt);
+    if (sync) HIPCHK(h, hipStreamSynchronize(st));
     return SLAMK_OK;
+}
+
+static bool same_mirror(const HostFilter& a, const HostFilter& b)
+{
+    return a.nf == b.nf && a.id == b.id && a.isref == b.isref;
 }
 
 int slamk_frame(slamk_handle* h, int b, const slamk_match* matches, int nmatch, const double quat[4])
 {
     if (!h || nmatch < 0 || (nmatch && !matches) || !quat) return SLAMK_EINVAL;
     ENTER_HOST(h);
-    FramePlan plan;
+    std::vector<FrameGroup> groups;
+    std::vector<int> grp;
     if (b >= 0) {
         CHECK_B(h, b);
-        int rc = plan_frame(h, h->hf[b], matches, nmatch, plan);
-        return rc ? rc : apply_frame(h, b, 1, plan, matches, nmatch, quat);
+        groups.resize(1);
+        groups[0].matches = matches; groups[0].nmatch = nmatch; groups[0].quat = quat;
+        int rc = plan_frame(h, h->hf[b], matches, nmatch, groups[0].plan);
+        if (rc) return rc;
+        grp.assign(1, 0);
+        return apply_frames(h, b, 1, groups, grp, 0, true);
     }
     // the same frame for every filter: runs of filters with identical feature lists share one plan
-    for (int i = 0; i < h->B;) {
-        int j = i + 1;
-        while (j < h->B && h->hf[j].nf == h->hf[i].nf && h->hf[j].id == h->hf[i].id && h->hf[j].isref == h->hf[i].isref) ++j;
-        int rc = plan_frame(h, h->hf[i], matches, nmatch, plan);
-        if (!rc) rc = apply_frame(h, i, j - i, plan, matches, nmatch, quat);
+    grp.resize(h->B);
+    for (int i = 0; i < h->B; ++i) {
+        if (i > 0 && same_mirror(h->hf[i], h->hf[i - 1])) { grp[i] = grp[i - 1]; continue; }
+        groups.emplace_back();
+        FrameGroup& g = groups.back();
+        g.matches = matches; g.nmatch = nmatch; g.quat = quat;
+        int rc = plan_frame(h, h->hf[i], matches, nmatch, g.plan);
         if (rc) return rc;
-        i = j;
+        grp[i] = (int)groups.size() - 1;
     }
-    return SLAMK_OK;
+    return apply_frames(h, 0, h->B, groups, grp, 0, true);
+}
+
+int slamk_frame_batch_async(slamk_handle* h, const slamk_match* matches, int nmatch, const int32_t* match_off,
+                            const double* quat, void* stream)
+{
+    if (!h || !quat || nmatch < 0) return SLAMK_EINVAL;
+    if (match_off) {
+        for (int b = 0; b < h->B; ++b)
+            if (match_off[b] < 0 || match_off[b + 1] < match_off[b]) return fail(h, SLAMK_EINVAL, "frame_batch: match_off must ascend");
+        if (match_off[h->B] > 0 && !matches) return SLAMK_EINVAL;
+    } else if (nmatch && !matches)
+        return SLAMK_EINVAL;
+    ENTER(h);
+    note_stream(h, stream);
+    std::vector<FrameGroup> groups;
+    std::vector<int> grp(h->B);
+    for (int i = 0; i < h->B; ++i) {
+        const slamk_match* mi = match_off ? matches + match_off[i] : matches;
+        const int ni = match_off ? match_off[i + 1] - match_off[i] : nmatch;
+        const double* qi = match_off ? quat + 4 * (size_t)i : quat;
+        if (i > 0 && same_mirror(h->hf[i], h->hf[i - 1])) {
+            // the same feature list and the same frame as the previous filter: the same plan
+            const FrameGroup& pg = groups[grp[i - 1]];
+            if (pg.nmatch == ni && (pg.matches == mi || memcmp(pg.matches, mi, (size_t)ni * sizeof(slamk_match)) == 0) &&
+                (pg.quat == qi || memcmp(pg.quat, qi, 4 * sizeof(double)) == 0)) {
+                grp[i] = grp[i - 1];
+                continue;
+            }
+        }
+        groups.emplace_back();
+        FrameGroup& g = groups.back();
+        g.matches = mi; g.nmatch = ni; g.quat = qi;
+        int rc = plan_frame(h, h->hf[i], mi, ni, g.plan);      // nothing has been queued yet when a plan fails
+        if (rc) return rc;
+        grp[i] = (int)groups.size() - 1;
+    }
+    return apply_frames(h, 0, h->B, groups, grp, (hipStream_t)stream, false);
 }
 
 int slamk_set_frame_values(slamk_handle* h, int b, const double* src2, const double* refl2)

@@ -129,6 +129,13 @@ class FilterBatch:
         q = _f64(quat, 4)
         self._chk(self.L.slamk_frame(self.h, b, arr, len(matches), _ptr(q)))
 
+    def frame_batch_async(self, matches, quat, match_off=None, stream=0):
+        """Frames of all filters, stream-ordered (slamk_frame_batch_async).  match_off None: one frame for all."""
+        arr = matches_array(matches)
+        q = _f64(quat, 4 if match_off is None else 4 * self.B)
+        off = None if match_off is None else np.ascontiguousarray(match_off, dtype=np.int32)
+        self._chk(self.L.slamk_frame_batch_async(self.h, arr, len(matches), _ptr(off), _ptr(q), stream))
+
     def set_frame_values(self, b, src, refl):
         nf = self.num_features(b)
         src, refl = _f64(src, 2 * nf), _f64(refl, 2 * nf)

@@ -130,3 +130,72 @@ def test_debug_switch_invalidates_captured_graphs():
     assert np.allclose(np.diag(Fm)[:6], 1.0) and np.abs(Fm).sum() > n       # a real Jacobian, not the zero fill
     assert np.abs(dbg["H"]).sum() > 0 and np.all(np.diag(dbg["L"]) > 0)
     fb.close()
+
+
+def test_batch_frames_on_a_stream_match_per_filter_frames():
+    """slamk_frame_batch_async (every filter its own frame, one upload, stream-ordered, no synchronisation) against
+    slamk_frame filter by filter: filters of one batch follow streams with different churn."""
+    import torch
+    B, nf = 6, 10
+    sts = [synth.gen_stream(seed=50 + b, nf=nf - (b % 3), steps=13, churn=True, image_every=1, retire_dx=8.3,
+                            drop_at=4 + b % 2, drop_count=2, add_at=8, add_count=3) for b in range(B)]
+    inps = [helpers.stream_inputs(st, 9) for st in sts]
+    dev = torch.device("cuda", 0)
+    z = torch.zeros(1, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    fbs = [ekf.FilterBatch(max_features=nf + 4, batch=B) for _ in range(2)]
+    for fb in fbs:
+        for b in range(B):
+            fb.set_state(b, X=sts[b].init_pos)
+
+    def frames(k):
+        allm, off, quats = [], [0], []
+        for b in range(B):
+            allm += inps[b][k][5]
+            off.append(len(allm))
+            quats.append(inps[b][k][1])
+        return allm, off, np.concatenate(quats)
+
+    allm, off, quats = frames(0)
+    for b in range(B):
+        fbs[0].frame(b, inps[b][0][5], inps[b][0][1])
+    fbs[1].frame_batch_async(allm, quats, off, stream.cuda_stream)
+    counts = set()
+    for k in range(1, 13):
+        q = np.concatenate([inps[b][k][1] for b in range(B)])
+        w = np.concatenate([inps[b][k][2] for b in range(B)])
+        a = np.concatenate([inps[b][k][3] for b in range(B)])
+        dt = np.array([inps[b][k][4] for b in range(B)])
+        d = {n: torch.tensor(v, device=dev) for n, v in (("q", q), ("w", w), ("a", a), ("dt", dt))}
+        torch.cuda.synchronize()
+        allm, off, quats = frames(k)
+        for b in range(B):
+            fbs[0].frame(b, inps[b][k][5], inps[b][k][1])
+        fbs[0].predict(q, w, a, dt)
+        fbs[0].update(q)
+        # no synchronisation between the frames and the step, nor after the step
+        fbs[1].frame_batch_async(allm, quats, off, stream.cuda_stream)
+        fbs[1].step_dev(d["q"].data_ptr(), d["w"].data_ptr(), d["a"].data_ptr(), d["dt"].data_ptr(), None, None, None,
+                        None, stream.cuda_stream)
+        counts.add(tuple(fbs[1].num_features(b) for b in range(B)))
+    fbs[1].sync(stream.cuda_stream)
+    assert len(counts) > 2
+    for b in range(B):
+        assert list(fbs[0].get_features(b)["ids"]) == list(fbs[1].get_features(b)["ids"])
+        assert np.array_equal(fbs[0].get_cov(b), fbs[1].get_cov(b))
+        assert np.array_equal(fbs[0].state_vector(b), fbs[1].state_vector(b))
+    # one frame for all (match_off None) == slamk_frame(-1)
+    m0 = inps[0][12][5]
+    fbs[0].frame(-1, m0, inps[0][12][1])
+    fbs[1].frame_batch_async(m0, inps[0][12][1], None, stream.cuda_stream)
+    fbs[1].sync(stream.cuda_stream)
+    for b in range(B):
+        assert list(fbs[0].get_features(b)["ids"]) == list(fbs[1].get_features(b)["ids"])
+        assert np.array_equal(fbs[0].get_cov(b), fbs[1].get_cov(b))
+    # a frame that does not fit: refused before anything is queued
+    big = [(1000 + i, 0.01 * i, 0.02, 0, 0) for i in range(nf + 5)]
+    with pytest.raises(ekf.SlamkError) as ei:
+        fbs[1].frame_batch_async(big, inps[0][12][1], None, stream.cuda_stream)
+    assert ei.value.code == -5
+    for fb in fbs:
+        fb.close()
