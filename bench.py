@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Benchmark of the EKF predict/update hot path on MI355X.
 
-Workload (BASELINE.json configs[2]): batched Monte Carlo, 4096 independent filters x 32
-features per GPU (n = 105, m = 161 with half of the features reflective), synthetic
-sensor_emu-style data.  One step = one loop iteration WITH an image for every filter of the
+Workload: batched Monte Carlo of independent filters x 32 features (n = 105, m = 161 with half of
+the features reflective), synthetic sensor_emu-style data.  One GPU: BASELINE.json configs[2], 4096
+filters.  N > 1 GPUs: configs[4], 65536 filters over 8 GPUs = 8192 filters per GPU (the same per-GPU
+shard at every N > 1; `config.workload` names what ran).  One step = one loop iteration WITH an image for every filter of the
 batch: frame begin (old_pos, depth clamp), predict (F, dynamics, P = F P F^T + Q) and update
 (measurement model + Jacobian, S, Cholesky gain, Joseph covariance update, gated mean update).
 All inputs of every step are resident in HBM before the timed region starts.
@@ -85,6 +86,57 @@ def cpu_baseline(st, steps, nf, k0, k1, budget_s=12.0, max_filters=256):
         cnt += 1
     return {"value": done / t_total, "unit": "EKF updates/s", "cores": 1, "kind": "port",
             "sample": "%d filters x %d steps (nf=%d) of the same batch, oracle/ekf_oracle.c orc_step, 1 thread" % (cnt, k1 - k0, nf)}
+
+
+def churn_workload(torch, dev, B, nf, K, rank):
+    """One step = image frame of every filter (association + covariance surgery) + predict + update, on a stream whose
+    features are retired and replaced; the frame is the same for all filters, their pixel noise is not."""
+    from slam_amd import ekf, synth
+    st = synth.gen_stream(seed=1, nf=nf, steps=K + 4, churn=True, image_every=1, ref_fraction=0.5, retire_dx=8.0,
+                          spawn_dx=(8.0, 9.0))
+    g = torch.Generator(device=dev)
+    g.manual_seed(77 + rank)
+    fb = ekf.FilterBatch(max_features=nf, batch=B, device=dev.index or 0)
+    for b in range(B):
+        fb.set_state(b, X=st.init_pos)
+    fb.frame(-1, first_frame(st), st.steps[0].quat)
+    stream = torch.cuda.Stream(device=dev)
+    steps, frames, replaced = [], [], 0
+    for k in range(1, K + 3):
+        s, prev = st.steps[k], st.steps[k - 1]
+        one = lambda v: torch.tensor(np.tile(np.asarray(v, dtype=np.float64), (B, 1)), device=dev)
+        src = torch.tensor(s.src.T.copy(), device=dev)
+        refl = torch.tensor(s.refl.T.copy(), device=dev)
+        has = (refl != 0).to(torch.float64)
+        steps.append({"qbw": one(s.quat), "w": one(s.ang), "acc": one(s.acc),
+                      "dt": torch.full((B,), s.t - prev.t, device=dev, dtype=torch.float64),
+                      "src": (src.unsqueeze(0) + st.noise * torch.randn((B, 2, nf), generator=g, device=dev, dtype=torch.float64)).contiguous(),
+                      "refl": (refl.unsqueeze(0) + st.noise * torch.randn((B, 2, nf), generator=g, device=dev, dtype=torch.float64) * has).contiguous()})
+        frames.append(([(int(s.ids[i]), s.src[i, 0], s.src[i, 1], s.refl[i, 0], s.refl[i, 1]) for i in range(nf)], s.quat))
+        if k >= 3:
+            replaced += int(np.sum(s.ids != prev.ids))
+    torch.cuda.synchronize(dev)
+
+    def run(k):
+        fb.frame_batch_async(frames[k][0], frames[k][1], None, stream.cuda_stream)
+        d = steps[k]
+        fb.step_dev(d["qbw"].data_ptr(), d["w"].data_ptr(), d["acc"].data_ptr(), d["dt"].data_ptr(), None,
+                    d["src"].data_ptr(), d["refl"].data_ptr(), None, stream.cuda_stream)
+    run(0); run(1)
+    fb.sync(stream.cuda_stream)
+    t0 = time.perf_counter()
+    for k in range(2, 2 + K):
+        run(k)
+    fb.sync(stream.cuda_stream)
+    t = time.perf_counter() - t0
+    ids_ok = list(fb.get_features(B - 1)["ids"]) == [int(i) for i in st.steps[K + 2].ids]
+    P = fb.get_cov(B // 3)
+    sane = bool(ids_ok and np.all(np.isfinite(P)) and np.array_equal(P, P.T) and np.all(np.diag(P) > 0))
+    fb.close()
+    return {"what": "slamk_frame_batch_async (one frame for all filters, features retired and replaced) + slamk_step_dev "
+                    "per step, same stream, no host synchronisation inside the timed region",
+            "updates_per_s": B * K / t, "ms_per_step": t / K * 1e3, "steps": K,
+            "features_replaced_per_step": replaced / K, "outputs_sane": sane}
 
 
 def ceilings(torch, dev):
@@ -226,7 +278,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch-per-gpu", type=int, default=4096)
+    ap.add_argument("--batch-per-gpu", type=int, default=0, help="default: 4096 on one GPU, 8192 on several")
     ap.add_argument("--nf", type=int, default=32)
     ap.add_argument("--groups", type=int, default=1, help="ranges of the batch pipelined on streams of their own")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -255,7 +307,8 @@ def main():
     torch.cuda.set_device(dev)
 
     from slam_amd import ekf
-    B, nf, K, W = args.batch_per_gpu, args.nf, args.steps, args.warmup
+    B = args.batch_per_gpu or (4096 if world == 1 else 8192)
+    nf, K, W = args.nf, args.steps, args.warmup
     st, steps = build_inputs(torch, dev, B, nf, W + K, rank)
     fb = ekf.FilterBatch(max_features=nf, batch=B, device=local)
     for b in range(B):
@@ -282,13 +335,18 @@ def main():
     fb.sync(stream.cuda_stream)
     fb.profile_enable(True)
     fb.profile_read()
+    # HIP events on the launch stream between the steps: per-step device times beside the wall clock
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
     barrier()
     t0 = time.perf_counter()
     for k in range(W, W + K):
+        marks[k - W].record(stream)
         run(k)
+    marks[K].record(stream)
     stream.synchronize()
     barrier()
     t = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(K))
     prof = fb.profile_read()
     fb.profile_enable(False)
     fb.sync(stream.cuda_stream)          # also raises on a per-filter status word
@@ -330,15 +388,23 @@ def main():
         fb.update(hs["qbw"])
     t_host = (time.perf_counter() - th0) / hk
 
+    # The same step with the image branch in front of it (src/slam/main.cpp:167-175 inside every iteration): a
+    # stream whose features are retired and replaced along the way; association on the host, covariance surgery
+    # on the device, queued on the same stream without synchronisation (slamk_frame_batch_async).
+    churn = churn_workload(torch, dev, B, nf, min(K, 10), rank) if (rank == 0 and not args.no_extra) else None
+
     if rank == 0:
         # Dominant kernel: gain_solver_kernel (W = P H^T, S = H W + R, tile Cholesky, K = W S^-1), one launch per step, timed
         # with HIP events on the launch stream.  Its algorithmic work is the 16^3 tile products it executes.
         nl, ml = (n + 15) // 16 * 16, (m + 15) // 16 * 16
         solver_ms = prof["gain_solver"][0] / K
-        solver_flops = B * ekf.flops_update_stage(n, m, 0, 0)
+        solver_exec_flops = B * ekf.flops_update_stage(n, m, 0, 0)          # 16^3 tile products as executed (padding included)
+        # algorithmic work of the stage, no padding: Cholesky m^3/3, two triangular solves with n right-hand sides
+        # 2 n m^2, W = P H^T 12 n m and the lower half of S = H W + R 6 m (m + 1) with the six-entry rows of H
+        solver_flops = B * (m ** 3 / 3.0 + 2.0 * n * m * m + 12.0 * n * m + 6.0 * m * (m + 1))
         achieved = solver_flops / (solver_ms * 1e-3) / 1e12
         pmc = {}
-        side = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        side = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if os.path.exists(side) and B == 4096 and nf == 32:      # the counters were collected on this workload
             try:
                 pmc = json.load(open(side))["kernels"]
@@ -350,13 +416,15 @@ def main():
                     return v["hbm_bytes_per_launch_fetch_doubled"]
             return None
         cov_ms = prof["gemm_cov_update"][0] / K
-        cov_flops = B * ekf.flops_update_stage(n, m, 0, 1)
+        cov_exec_flops = B * ekf.flops_update_stage(n, m, 0, 1)
+        cov_flops = B * (3.0 * n ** 3 + 1.0 * n * n * m)      # A P 2n^3, lower (A P) A^T n^3, lower K R K^T n^2 m
         pred_ms = prof["struct_predict"][0] / K
         pred_bytes = 2.0 * B * nl * nl * 8
         kernels = [
             {"kernel": "joseph_kernel (A = I - K H, A P, (A P) A^T + K R K^T)", "bound": "mfma", "ms": cov_ms,
              "achieved": cov_flops / (cov_ms * 1e-3) / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-             "frac": cov_flops / (cov_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS, "traffic": pmc_bytes("joseph_kernel")},
+             "frac": cov_flops / (cov_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS, "traffic": pmc_bytes("joseph_kernel"),
+             "executed_tile_flops_frac": cov_exec_flops / (cov_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS},
             {"kernel": "predict_cov_kernel (P = F P F^T + Q, F in compact row form)", "bound": "hbm", "ms": pred_ms,
              "achieved": pred_bytes / (pred_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": pred_bytes / (pred_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_bytes("predict_cov_kernel")},
@@ -367,22 +435,30 @@ def main():
             "metric": "EKF updates/sec (state dim, batch) + fp64 MFMA % of peak, 1/2/4/8 GPUs",
             "value": world * B * K / t, "unit": "EKF updates/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": t / K * 1e3,
+            "step_ms_device": {"min": step_ms[0], "median": step_ms[K // 2], "max": step_ms[-1],
+                               "what": "HIP events on the launch stream between consecutive steps (rank 0)"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "batched Monte Carlo: %d independent filters x %d features per GPU "
+            "config": {"workload": "%s: batched Monte Carlo, %d independent filters x %d features per GPU x %d GPU%s "
                                    "(state dim n=%d, measurement dim m=%d), one step = predict + image update of "
-                                   "every filter" % (B, nf, n, m),
+                                   "every filter" % ("BASELINE configs[2]" if world == 1 else
+                                                     "BASELINE configs[4] (65536 filters over 8 GPUs) per-GPU shard",
+                                                     B, nf, world, "" if world == 1 else "s", n, m),
                        "batch_per_gpu": B, "features": nf, "state_dim": n, "meas_dim": m,
                        "update_form": "cholesky gain + joseph covariance", "parallelism": "filters sharded x%d" % world,
                        "pipeline_groups": args.groups},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": pmc_bytes("gain_solver_kernel"),
-                         "kernel": "gain_solver_kernel<%d>: one launch per step, %d launches timed with HIP events on "
-                                   "the launch stream" % (ml // 16, prof["gain_solver"][1]),
+                         "kernel": "gain_solver_kernel<%d, border>: one launch per step, %d launches timed with HIP events "
+                                   "on the launch stream" % ((m - 1) // 16 if (m - 1) % 16 == 0 else ml // 16,
+                                                             prof["gain_solver"][1]),
                          "flops_per_launch": solver_flops, "ms_per_launch": solver_ms,
+                         "flops_what": "algorithmic, unpadded: m^3/3 + 2 n m^2 + 12 n m + 6 m (m + 1) per filter",
+                         "executed_tile_flops_per_launch": solver_exec_flops,
+                         "executed_tile_flops_frac": solver_exec_flops / (solver_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
                          "fp64_mfma_frac_all_mfma_kernels": (solver_flops + cov_flops) / (mfma_ms * 1e-3) / 1e12
                                                             / FP64_MATRIX_PEAK_TFLOPS,
-                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, FETCH_SIZE doubled)"},
+                         "traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc, FETCH_SIZE doubled)"},
             "other_kernels": kernels,
             # the dense formulation's work (8n^3 + 6n^2 m + 4nm^2 + m^3/3 + 2nm per update) priced at the measured rate:
             # what an all-GEMM pipeline would have to sustain to match `value`; the sparse Jacobian products skip
@@ -395,6 +471,8 @@ def main():
             "stages_ms_per_step": {k: round(v[0] / K, 4) for k, v in prof.items()},
             "outputs_sane": sane,
         }
+        if churn is not None:
+            out["churn_workload"] = churn
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(st, steps, nf, W, W + K)
         fb.close()

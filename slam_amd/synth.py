@@ -96,13 +96,15 @@ class Stream:
 
 def gen_stream(seed=1, nf=20, steps=90, ref_fraction=0.5, image_every=3, rate_hz=30.0,
                churn=True, retire_dx=4.0, attitude=True, noise=1e-3, t0=1.0,
-               drop_at=None, drop_count=0, add_at=None, add_count=0):
+               drop_at=None, drop_count=0, add_at=None, add_count=0, spawn_dx=(8.0, 20.0)):
     """Build a stream of `steps` time steps with `nf` live features.
 
     churn       : retire features closer than `retire_dx` ahead and replace them by a new id
                   (exercises in-place slot replacement of the association step).
     drop_at/add_at : step indices at which `drop_count` features vanish without replacement /
                   `add_count` extra features appear (exercises deletion and append).
+    spawn_dx    : range of the distance ahead at which features appear (a narrow range just above
+                  `retire_dx` gives a steady turnover of features).
     """
     rng = np.random.Generator(np.random.PCG64(seed))
     dt = 1.0 / rate_hz
@@ -118,7 +120,7 @@ def gen_stream(seed=1, nf=20, steps=90, ref_fraction=0.5, image_every=3, rate_hz
         return yaw_pitch_quat(0.08 * np.sin(0.4 * t), 0.05 * np.sin(0.3 * t + 0.5))
 
     def spawn(X, k):
-        return X + np.stack([rng.uniform(8, 20, k), rng.uniform(-4, 4, k), rng.uniform(-3, -0.5, k)], axis=1)
+        return X + np.stack([rng.uniform(spawn_dx[0], spawn_dx[1], k), rng.uniform(-4, 4, k), rng.uniform(-3, -0.5, k)], axis=1)
 
     n_ref = int(round(ref_fraction * nf))
     next_id = 0
