@@ -32,6 +32,8 @@ struct Point2d {
     Point2d() {}
     Point2d(double a, double b) : x(a), y(b) {}
     bool operator!=(const Point2d& o) const { return x != o.x || y != o.y; }
+    bool operator==(const Point2d& o) const { return x == o.x && y == o.y; }
+    Point2d operator-(const Point2d& o) const { return Point2d(x - o.x, y - o.y); }
 };
 struct Matx33d {
     double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -183,8 +185,102 @@ class ImageSensor {
     FILE* fp;
 };
 
-// include/states.h:21-59 -- the state lives on the GPU; this object is the handle plus the few
-// host-visible members main() touches.  Errors print the reference's message and exit(1).
+#define NONREF Point2d(0, 0)         // include/featureIO.h:25
+
+// include/feature.h:15-25
+struct frame {
+    Vec3d world, body;
+};
+struct inits {
+    Quaternion quaternion;
+    double inverse_depth = 0;
+    Vec3d anchor;
+    Point2d pib;
+    bool isRef = false;
+};
+typedef struct inits Inits;
+typedef struct frame Frame;
+
+// include/feature.h:30-222 -- read-only mirror of one tracked feature (States::features is refreshed from the
+// device by States::pull_features): same member and accessor names; the prediction methods (xibHat ... ppbHat,
+// src/ARC/feature.cpp:143-198) run inside the measurement kernel and have no host copy.
+class Feature {
+   public:
+    Feature() {}
+    inits initial;
+    int getID() const { return ID; }
+    Vec3d get_body_position() const { return position.body; }                      // feature.h:101-105
+    Vec3d get_initial_anchor() const { return initial.anchor; }                    // :150-154
+    Quaternion get_initial_quaternion() const { return initial.quaternion; }       // :170-174
+    Point2d get_initial_pib() const { return initial.pib; }
+    bool get_isRef() const { return initial.isRef; }
+    int get_noMatch() const { return noMatch; }                                    // :196-200
+    Feature& setID(int n) { ID = n; return *this; }
+    Feature& set_body(const Vec3d& pos) { position.body = pos; return *this; }
+    void set_body_position(const Vec3d& value) { position.body = value; }
+    void set_initial_anchor(const Vec3d& value) { initial.anchor = value; }
+    void set_initial_quaternion(const Quaternion& value) { initial.quaternion = value; }
+    void set_initial_pib(const Point2d& p) { initial.pib = p; }
+    void set_isRef(bool b) { initial.isRef = b; }
+    void set_noMatch(int value) { noMatch = value; }
+
+   private:
+    frame position;
+    int noMatch = 0;
+    int ID = 0;
+};
+typedef std::vector<Feature> active;
+typedef active::iterator Fiter;
+typedef active::const_iterator cFiter;
+
+// include/view.hpp:11-30
+struct vfeat {
+    vfeat(const Point2d& cur, const Point2d& init, const Point2d& refl) : current(cur), initial(init), reflection(refl) {}
+    vfeat(const Point2d& cur, const Point2d& init) : current(cur), initial(init), reflection(NONREF) {}
+    vfeat(const Vec3d& cur, const Vec3d& init, const Vec3d& refl)
+        : current(Point2d(cur[0], cur[1])), initial(Point2d(init[0], init[1])), reflection(Point2d(refl[0], refl[1])) {}
+    vfeat(const Vec3d& cur, const Vec3d& init)
+        : current(Point2d(cur[0], cur[1])), initial(Point2d(init[0], init[1])), reflection(NONREF) {}
+    Point2d current, initial, reflection;
+};
+typedef struct vfeat Vfeat;
+
+// include/view.hpp:38-66, src/ARC/view.cpp:3-47: the measurement vector as the reference orders it (altitude, then per
+// feature current, initial and -- only when its x is not 0 -- reflection); `toMat` flattens into a std::vector here.
+class View {
+   public:
+    View() : altitude(0) {}
+    void toMat(std::vector<double>& R) const
+    {
+        R.clear();
+        R.push_back(altitude);
+        for (std::vector<Vfeat>::const_iterator it = features.begin(); it != features.end(); ++it) {
+            R.push_back(it->current.x);
+            R.push_back(it->current.y);
+            R.push_back(it->initial.x);
+            R.push_back(it->initial.y);
+            if (it->reflection.x != 0) {           // features with no reflection add no rows
+                R.push_back(it->reflection.x);
+                R.push_back(it->reflection.y);
+            }
+        }
+    }
+    double altitude;
+    std::vector<Vfeat> features;
+};
+inline void subtract(const View& lhs, const View& rhs, View& dst)
+{
+    dst.altitude = lhs.altitude - rhs.altitude;
+    std::vector<Vfeat>::const_iterator lt = lhs.features.begin(), rt = rhs.features.begin();
+    for (; lt != lhs.features.end(); ++lt, ++rt) {
+        Point2d reflection(0, 0);
+        if (lt->reflection.x != 0) reflection = lt->reflection - rt->reflection;
+        dst.features.push_back(Vfeat(lt->current - rt->current, lt->initial - rt->initial, reflection));
+    }
+}
+
+// include/states.h:21-59 -- the state lives on the GPU; this object is the handle plus the host-visible
+// members of the reference's class (X, V, b, features, rf, nrf).  Errors print the reference's message and exit(1).
 class States {
    public:
     explicit States(int max_features)
@@ -195,6 +291,35 @@ class States {
     }
     ~States() { if (h) slamk_destroy(h); }
     Vec3d X, V, b;
+    active features;                 // mirror of the device containers, refreshed by pull_features()
+    int rf = 0, nrf = 0;             // features initialised with / without a reflection (states.cpp:203-211)
+    Vec3d getX() { return X; }
+    Vec3d getV() { return V; }
+    Vec3d getb() { return b; }
+    // Downloads the feature containers: slot order, ids and values as the reference's `features` vector holds them.
+    void pull_features()
+    {
+        const int nf = getNumFeatures();
+        std::vector<int32_t> id(nf + 1);
+        std::vector<double> pib(3 * nf + 1), anchor(3 * nf + 1), q0(4 * nf + 1), pib0(2 * nf + 1);
+        std::vector<uint8_t> isr(nf + 1);
+        int n = 0;
+        if (slamk_get_features(h, 0, &n, id.data(), pib.data(), anchor.data(), q0.data(), pib0.data(), isr.data()))
+            die("get_features");
+        features.assign(nf, Feature());
+        rf = nrf = 0;
+        for (int i = 0; i < nf; ++i) {
+            Feature& f = features[i];
+            f.setID(id[i]);
+            f.set_body_position(Vec3d(pib[3 * i], pib[3 * i + 1], pib[3 * i + 2]));
+            f.initial.anchor = Vec3d(anchor[3 * i], anchor[3 * i + 1], anchor[3 * i + 2]);
+            f.initial.quaternion = Quaternion(q0[4 * i], q0[4 * i + 1], q0[4 * i + 2], q0[4 * i + 3]);
+            f.initial.pib = Point2d(pib0[2 * i], pib0[2 * i + 1]);
+            f.initial.inverse_depth = pib[3 * i + 2];
+            f.initial.isRef = isr[i] != 0;
+            if (f.initial.isRef) ++rf; else ++nrf;
+        }
+    }
     int getNumFeatures() const { return slamk_num_features(h, 0); }
     int getRows() const { return 9 + 3 * getNumFeatures(); }
     void pushX() { if (slamk_set_state(h, 0, X.v, nullptr, nullptr)) die("set_state"); }

@@ -72,8 +72,19 @@ class Stream:
         refl = s.refl + self.noise * rng.standard_normal(s.refl.shape) * has[:, None]
         return src, refl
 
-    def to_text(self, noise_seed=None):
-        """Return (sensors_text, features_text) for the `slam <features> < sensors` front end."""
+    def to_text(self, noise_seed=None, pos_every=0, vel_every=0, alt=False, no_acc_every=0, no_acc_ang_every=0,
+                alt_only_after=None):
+        """Return (sensors_text, features_text) for the `slam <features> < sensors` front end.
+
+        pos_every / vel_every : every k-th step also carries a POS line (x and y swapped on the wire, as the
+                    estimator swaps them back, reference: src/slam/main.cpp:180-185) / a VEL line (world-frame
+                    velocity, turned into the body frame by the estimator, :186-191), both slightly off the truth.
+        alt       : every step carries an ALT line (the value is overridden by the estimator, :177).
+        no_acc_every / no_acc_ang_every : every k-th step lacks its ACC line / its ACC and ANG lines, so that the
+                    step length falls back to the ANG / QUAT channel (:158-166); the next ACC line then spans two steps.
+        alt_only_after : index of a step after which a group holding nothing but an ALT line is inserted
+                    (2 ms later; step length from the ALT channel, a predict-only iteration).
+        """
         rng = np.random.Generator(np.random.PCG64(self.seed if noise_seed is None else noise_seed))
         sens, feat = [], []
         for k, s in enumerate(self.steps):
@@ -83,14 +94,28 @@ class Stream:
                 p = self.init_pos
                 sens.append("%.6f,INIT,%.17g,%.17g,%.17g" % (t, p[1], p[0], p[2]))
             sens.append("%.6f,QUAT,%.17g,%.17g,%.17g,%.17g" % (t, *s.quat))
-            sens.append("%.6f,ANG,%.17g,%.17g,%.17g" % (t, *s.ang))
-            sens.append("%.6f,ACC,%.17g,%.17g,%.17g" % (t, *s.acc))
+            skip_ang = bool(no_acc_ang_every and k > 0 and k % no_acc_ang_every == 0)
+            skip_acc = skip_ang or bool(no_acc_every and k > 0 and k % no_acc_every == 0)
+            if not skip_ang:
+                sens.append("%.6f,ANG,%.17g,%.17g,%.17g" % (t, *s.ang))
+            if not skip_acc:
+                sens.append("%.6f,ACC,%.17g,%.17g,%.17g" % (t, *s.acc))
+            if alt:
+                sens.append("%.6f,ALT,%.17g" % (t, -s.X_true[2] + 0.01 * np.sin(k)))
+            if pos_every and k > 0 and k % pos_every == 0:
+                p = s.X_true + np.array([0.01, -0.02, 0.003])
+                sens.append("%.6f,POS,%.17g,%.17g,%.17g" % (t, p[1], p[0], p[2]))
+            if vel_every and k > 0 and k % vel_every == 0 and k + 1 < len(self.steps):
+                v = (self.steps[k + 1].X_true - s.X_true) / self.dt + np.array([0.01, 0.0, -0.01])
+                sens.append("%.6f,VEL,%.17g,%.17g,%.17g" % (t, *v))
             if s.image:
                 sens.append("%.6f,IMG,0" % t)
                 src, refl = self.noisy_frame(k, rng)
                 for i in range(len(s.ids)):
                     feat.append("%d,%.17g,%.17g,%.17g,%.17g" % (s.ids[i], src[i, 0], src[i, 1], refl[i, 0], refl[i, 1]))
                 feat.append("")
+            if alt_only_after is not None and k == alt_only_after:
+                sens.append("%.6f,ALT,%.17g" % (t + 0.012, -s.X_true[2]))
         return "\n".join(sens) + "\n", "\n".join(feat) + "\n"
 
 

@@ -37,6 +37,68 @@ def test_stdout_matches_oracle_front_end(seed, nf):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("opts", [dict(pos_every=7), dict(vel_every=5), dict(alt=True, alt_only_after=10),
+                                  dict(no_acc_every=4), dict(no_acc_ang_every=6, alt=True),
+                                  dict(pos_every=9, vel_every=11, alt=True, no_acc_every=5, alt_only_after=20)])
+def test_position_velocity_altimeter_lines_and_step_length_fallbacks(opts):
+    """POS / VEL overrides (main.cpp:180-191), ALT lines, and groups whose step length comes from the ANG, QUAT or ALT
+    channel because ACC is missing (:158-166): stdout byte for byte as the oracle's front end."""
+    st = synth.gen_stream(seed=9, nf=8, steps=46, churn=True, drop_at=15, drop_count=2, add_at=30, add_count=2)
+    sens, feat = st.to_text(**opts)
+    for tag in ("POS" if opts.get("pos_every") else None, "VEL" if opts.get("vel_every") else None,
+                "ALT" if opts.get("alt") else None):
+        assert tag is None or (",%s," % tag) in sens
+    with tempfile.TemporaryDirectory() as d:
+        fp = os.path.join(d, "features.txt")
+        open(fp, "w").write(feat)
+        rc_o, out_o, err_o = orc.slam_run(sens, fp)
+        r = subprocess.run([SLAM, fp], input=sens, capture_output=True, text=True, timeout=120)
+        assert rc_o == 0 and r.returncode == 0, (err_o, r.stderr)
+        groups = 46 + (1 if opts.get("alt_only_after") is not None else 0)
+        assert len(r.stdout.split("\n")) == groups
+        assert r.stdout == out_o
+
+
+@pytest.mark.gpu
+def test_group_without_any_known_sensor_line():
+    """A group that carries none of the known line types: "No update, so what are we doing here?" and exit 1 (:162-166)."""
+    st = synth.gen_stream(seed=9, nf=4, steps=4, churn=False)
+    sens, feat = st.to_text()
+    sens += "9.000000,FOO,1,2,3\n9.100000,FOO,1,2,3\n"
+    with tempfile.TemporaryDirectory() as d:
+        fp = os.path.join(d, "features.txt")
+        open(fp, "w").write(feat)
+        rc_o, out_o, err_o = orc.slam_run(sens, fp)
+        r = subprocess.run([SLAM, fp], input=sens, capture_output=True, text=True, timeout=60)
+        assert rc_o == 1 and r.returncode == 1
+        assert "No update, so what are we doing here?" in r.stderr and "No update" in err_o
+        assert r.stdout == out_o
+
+
+@pytest.mark.gpu
+def test_host_type_mirrors_against_the_device():
+    """host/typecheck: code written with the reference's member names (Feature, View, States::features / rf / nrf)
+    builds against the host header and sees what the device holds."""
+    r = subprocess.run([os.path.join(ROOT, "host", "typecheck"), "gpu"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().split("\n")
+    assert lines[0].startswith("rows 11:") and lines[1] == "refl flags 1 0"
+    assert "nf 3 rf 1 nrf 2 rows 18" in lines
+    assert lines[-3].startswith("id 10 pib 0 -0.05 0.01 anchor 0.5 -0.25 1.34 q0w 0.99") and lines[-2].split()[-1] == "1"
+
+
+def test_host_type_mirrors_compile_and_flatten_like_the_reference():
+    """View::toMat / subtract (src/ARC/view.cpp:3-47): reflection rows only where the left operand's reflection x is
+    not 0; runs without a GPU."""
+    r = subprocess.run([os.path.join(ROOT, "host", "typecheck")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    vals = [float(x) for x in r.stdout.split("\n")[0].split(":")[1].split()]
+    exp = [-1.34 + 1.30, 0.1 - 0.11, 0.2 - 0.19, 0.3 - 0.29, 0.4 - 0.41, 0.5 - 0.52, 0.6 - 0.57, 1.1 - 1.0, 1.2 - 1.0,
+           1.3 - 1.0, 1.4 - 1.0]
+    assert vals == exp
+
+
+@pytest.mark.gpu
 def test_missing_image_in_first_group():
     with tempfile.NamedTemporaryFile("w", suffix=".txt") as fp:
         fp.write("1,0.1,0.1,0,0\n\n")
