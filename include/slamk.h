@@ -30,6 +30,7 @@
 #ifndef SLAMK_H
 #define SLAMK_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -222,6 +223,35 @@ int slamk_buffer_dev(slamk_handle* h, int which, double** ptr, int* rows, int* c
  * int32 in device memory that gets bit 1 set when S is not positive definite (the caller zeroes and reads it). */
 int slamk_cholesky_inverse_dev(double* S_dev, double* L_dev, double* Li_dev, int m, int ld, int32_t* status_dev,
                                void* stream);
+
+/* ---- one large-map filter, covariance sharded by row blocks over the GPUs of a node (one process per GPU) ----
+ * No counterpart in the reference (a single-threaded program); the arithmetic is calcP / calcK / updateP (Joseph
+ * form) / the gated mean update of src/slam/main.cpp:526-530,539-552,561-569,228-232 on a row-distributed P.
+ * `h` is a handle with batch 1 that every rank creates and feeds with the SAME frames and sensors (the O(nf) state
+ * is replicated); rank r owns rows [r bn, (r + 1) bn) of P.  Collectives: RCCL all-gathers on the caller's stream,
+ * through a communicator the library creates from the id of slamk_nccl_unique_id (obtained on one rank and handed to
+ * the others by the caller), or through the caller's own in-place all-gather `allgather` (non-NULL: `nccl_id` is
+ * ignored), which must gather `bytes_per_rank` bytes per rank inside `buf_dev` (rank r's part at offset
+ * r * bytes_per_rank), ordered on `stream`, and return 0. */
+#define SLAMK_NCCL_ID_BYTES 128
+typedef struct slamk_sharded slamk_sharded;
+typedef int (*slamk_allgather_fn)(void* ctx, void* buf_dev, size_t bytes_per_rank, int rank, int world, void* stream);
+int slamk_nccl_unique_id(void* id /* SLAMK_NCCL_ID_BYTES bytes */);
+int slamk_sharded_create(slamk_handle* h, int rank, int world, const void* nccl_id, slamk_allgather_fn allgather, void* ctx,
+                         slamk_sharded** out);
+int slamk_sharded_destroy(slamk_sharded* s);
+/* Distributes a full n x n covariance (device memory, the same on every rank): keeps this rank's rows and allocates
+ * the rank's workspaces for the current feature set (call again after the feature set changes). */
+int slamk_sharded_load_cov_dev(slamk_sharded* s, const double* P_full_dev, int ld, void* stream);
+int slamk_sharded_predict_dev(slamk_sharded* s, const double* qbw_dev, const double* w_dev, const double* acc_dev,
+                              const double* dt_dev, void* stream);
+int slamk_sharded_update_dev(slamk_sharded* s, const double* qbw_dev, const double* alt_dev, const double* src_dev,
+                             const double* refl_dev, int32_t* applied_dev, void* stream);
+/* The full n x n covariance on every rank (one all-gather). */
+int slamk_sharded_gather_cov_dev(slamk_sharded* s, double* P_full_dev, int ld, void* stream);
+/* Dimensions of the sharded layout; any pointer may be NULL. */
+int slamk_sharded_dims(slamk_sharded* s, int* n, int* m, int* rows_per_rank, int* srows_per_rank, int* n_padded,
+                       int* m_padded);
 
 /* Tuning of the large-matrix path, process-wide (0 = leave as is): the outer panel width of the two-level
  * blocked Cholesky (multiple of 128, default 512) and the rows of the diagonal blocks of L that are inverted for

@@ -43,16 +43,18 @@ def main():
         else:
             dist.init_process_group(backend)
     from slam_amd import ekf, synth
-    from slam_amd.sharded import HipBackend, ShardedLargeMapFilter
+    from slam_amd.sharded import ShardedFilter
     nf = args.nf
     st = synth.gen_stream(seed=2, nf=nf, steps=args.steps + args.warmup + 1, churn=False, image_every=1)
     fb = ekf.FilterBatch(max_features=nf, batch=1, device=local)
     fb.set_state(0, X=st.init_pos)
     s0 = st.steps[0]
     fb.frame(0, [(int(s0.ids[i]), s0.src[i, 0], s0.src[i, 1], s0.refl[i, 0], s0.refl[i, 1]) for i in range(nf)], s0.quat)
-    be = HipBackend(fb, dev)
-    sh = ShardedLargeMapFilter(be, rank, world)
-    sh.load_cov(torch.from_numpy(fb.get_cov(0)).to(dev))
+    stream = torch.cuda.Stream(device=dev)
+    sh = ShardedFilter(fb, rank, world, None, device=dev, stream=stream)
+    P0 = torch.from_numpy(fb.get_cov(0)).to(dev)
+    torch.cuda.synchronize(dev)
+    sh.load_cov(P0)
     t = lambda v: torch.tensor(np.asarray(v, dtype=np.float64), device=dev)
     rng = np.random.default_rng(5)
 
@@ -61,9 +63,11 @@ def main():
         src = s.src + st.noise * rng.standard_normal(s.src.shape)
         refl = s.refl + st.noise * rng.standard_normal(s.refl.shape) * (s.refl != 0)
         fb.set_frame_values(0, src, refl)
-        fb.frame_begin_dev(be.sptr)
-        sh.predict(t(s.quat), t(s.ang), t(s.acc), t([s.t - st.steps[k - 1].t]))
-        sh.update(t(s.quat))
+        q, w, a, d = t(s.quat), t(s.ang), t(s.acc), t([s.t - st.steps[k - 1].t])
+        torch.cuda.synchronize(dev)
+        fb.frame_begin_dev(sh.sptr)
+        sh.predict(q, w, a, d)
+        sh.update(q)
 
     for k in range(1, 1 + args.warmup):
         step(k)
@@ -77,7 +81,7 @@ def main():
     if world > 1:
         dist.barrier()
     dtm = (time.perf_counter() - t0) / args.steps
-    n, m = sh.n, sh.m
+    n, m = sh.dims()["n"], sh.dims()["m"]
     dense = 8.0 * n**3 + 6.0 * n * n * m + 4.0 * n * m * m + m**3 / 3.0
     P = sh.gather_cov()
     ok = bool(torch.isfinite(P).all().item() and (torch.diagonal(P) > 0).all().item())

@@ -62,6 +62,14 @@ SIGNATURES = {
     "slamk_stage_apply_dev": (C.c_int, [_H, _vp, C.c_int, _vp, _vp]),
     "slamk_buffer_dev": (C.c_int, [_H, C.c_int, C.POINTER(_vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "slamk_cholesky_inverse_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "slamk_nccl_unique_id": (C.c_int, [_vp]),
+    "slamk_sharded_create": (C.c_int, [_H, C.c_int, C.c_int, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "slamk_sharded_destroy": (C.c_int, [_vp]),
+    "slamk_sharded_load_cov_dev": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "slamk_sharded_predict_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "slamk_sharded_update_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "slamk_sharded_gather_cov_dev": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "slamk_sharded_dims": (C.c_int, [_vp] + [C.POINTER(C.c_int)] * 6),
     "slamk_pre_euler2qbw_dev": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "slamk_pre_rotate_dev": (C.c_int, [C.POINTER(C.c_double), _vp, _vp, C.c_int, _vp]),
     "slamk_pre_img2body_dev": (C.c_int, [_vp, _vp, C.c_int, _vp]),

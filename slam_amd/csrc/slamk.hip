@@ -3,6 +3,8 @@
 #include "../../include/slamk.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -1616,6 +1618,262 @@ int slamk_cholesky_inverse_dev(double* S_dev, double* L_dev, double* Li_dev, int
     static thread_local slamk_handle scratch_handle;   // error text / profiling sink for the handle-free call
     return cholesky_inverse(&scratch_handle, S_dev, L_dev, Li_dev, ld, (long long)ld * m, 1, m, status_dev,
                             (hipStream_t)stream);
+}
+
+// ---- one large-map filter sharded by row blocks over the GPUs of a node ------------------------------------
+// Rank r owns rows [r bn, (r + 1) bn) of P and of every n-row product (T = P F^T, W = P H^T, K, A) and rows
+// [r bm, (r + 1) bm) of S.  The O(nf) filter state is replicated: every rank runs the per-feature kernels itself and
+// holds the compact rows of F and H, so the products with the Jacobians are local sweeps over the rank's row block and
+// the only traffic is one all-gather per dense contraction (RCCL over xGMI, in place, on the caller's stream):
+//     predict:  T_r = P_r F^T -> all-gather T -> P_r = F_r T + Q_r                      (calcP, main.cpp:526-530)
+//     update :  W_r = P_r H^T -> all-gather W -> S_q = H_q W + R_q -> all-gather S      (calcK, :539-552)
+//               S = L L^T and the inverses of L's diagonal blocks (replicated)
+//               K_r = W_r L^-T L^-1 -> all-gather K;  A_r = I_r - K_r H -> all-gather A, all-gather P
+//               P_r <- (A_r P) A^T + (K_r R) K^T                                        (Joseph form of updateP, :561-569)
+//               dx = K e, gate, mean update (replicated)                                (:228-232)
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+// The collective library is opened on first use: a process that never shards a filter does not load it.
+static const RcclApi* rccl_api()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return;
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(lib, "ncclAllGather"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+        if (api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.GetErrorString) api.lib = lib;
+    });
+    return api.lib ? &api : nullptr;
+}
+
+struct slamk_sharded {
+    slamk_handle* h = nullptr;
+    int rank = 0, world = 1;
+    ncclComm_t comm = nullptr;
+    slamk_allgather_fn ag = nullptr;
+    void* ag_ctx = nullptr;
+    int n = 0, m = 0, bn = 0, bm = 0, N = 0, M = 0, r0 = 0, q0 = 0;
+    double *P = nullptr, *G1 = nullptr, *G2 = nullptr, *Ar = nullptr, *AP = nullptr, *W = nullptr, *K = nullptr, *Y = nullptr,
+           *KR = nullptr, *S = nullptr, *Lm = nullptr, *Li = nullptr, *rfull = nullptr;
+    std::vector<void*> allocs;
+};
+
+// rows [lo, hi) of the padded S: zero with a unit diagonal (rows the measurement operator does not have)
+__global__ void pad_identity_rows_kernel(double* __restrict__ S, int ld, int lo, int hi)
+{
+    const int r = lo + blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (r < hi && c < ld) S[(long long)r * ld + c] = (c == r) ? 1.0 : 0.0;
+}
+__global__ void fill_kernel(double* __restrict__ x, int n, double v)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = v;
+}
+
+static int sharded_free(slamk_sharded* s)
+{
+    for (void* p : s->allocs) (void)hipFree(p);
+    s->allocs.clear();
+    s->P = nullptr;
+    return 0;
+}
+
+// In-place all-gather of `full`: this rank's block_elems doubles sit at full + rank * block_elems.
+static int sharded_allgather(slamk_sharded* s, double* full, size_t block_elems, hipStream_t st)
+{
+    if (s->world == 1 && !s->comm) return 0;
+    if (s->ag) {
+        int rc = s->ag(s->ag_ctx, full, block_elems * sizeof(double), s->rank, s->world, (void*)st);
+        return rc ? fail(s->h, SLAMK_EHIP, "sharded: the caller's all-gather returned %d", rc) : 0;
+    }
+    const RcclApi* api = rccl_api();
+    ncclResult_t r = api->AllGather(full + (size_t)s->rank * block_elems, full, block_elems, ncclDouble, s->comm, st);
+    if (r != ncclSuccess) return fail(s->h, SLAMK_EHIP, "ncclAllGather: %s", api->GetErrorString(r));
+    return 0;
+}
+
+static int sharded_check(slamk_sharded* s)
+{
+    if (!s || !s->h) return SLAMK_EINVAL;
+    if (!s->P) return fail(s->h, SLAMK_EINVAL, "sharded: no covariance loaded (slamk_sharded_load_cov_dev)");
+    if (s->n != 9 + 3 * s->h->hf[0].nf || s->m != s->h->hf[0].m())
+        return fail(s->h, SLAMK_EINVAL, "sharded: the feature set changed since the covariance was loaded");
+    return 0;
+}
+
+int slamk_nccl_unique_id(void* id)
+{
+    const RcclApi* api = rccl_api();
+    if (!id || !api) return SLAMK_EHIP;
+    static_assert(sizeof(ncclUniqueId) == SLAMK_NCCL_ID_BYTES, "id size");
+    return api->GetUniqueId(static_cast<ncclUniqueId*>(id)) == ncclSuccess ? SLAMK_OK : SLAMK_EHIP;
+}
+
+int slamk_sharded_create(slamk_handle* h, int rank, int world, const void* nccl_id, slamk_allgather_fn allgather, void* ctx,
+                         slamk_sharded** out)
+{
+    if (!h || !out || world < 1 || rank < 0 || rank >= world) return SLAMK_EINVAL;
+    if (h->B != 1) return fail(h, SLAMK_EINVAL, "sharded: the handle must hold one filter");
+    ENTER(h);
+    slamk_sharded* s = new slamk_sharded();
+    s->h = h; s->rank = rank; s->world = world; s->ag = allgather; s->ag_ctx = ctx;
+    if (!allgather && (world > 1 || nccl_id)) {      // (an id with world == 1 makes a one-rank communicator: same code path)
+        const RcclApi* api = rccl_api();
+        if (!api) { delete s; return fail(h, SLAMK_EHIP, "sharded: librccl.so could not be loaded"); }
+        if (!nccl_id) { delete s; return fail(h, SLAMK_EINVAL, "sharded: world > 1 needs the shared id of slamk_nccl_unique_id"); }
+        ncclUniqueId id;
+        memcpy(&id, nccl_id, sizeof id);
+        ncclResult_t r = api->CommInitRank(&s->comm, world, id, rank);
+        if (r != ncclSuccess) { delete s; return fail(h, SLAMK_EHIP, "ncclCommInitRank: %s", api->GetErrorString(r)); }
+    }
+    *out = s;
+    return SLAMK_OK;
+}
+
+int slamk_sharded_destroy(slamk_sharded* s)
+{
+    if (!s) return SLAMK_EINVAL;
+    DeviceGuard dg_(s->h->device);
+    (void)hipDeviceSynchronize();
+    sharded_free(s);
+    if (s->comm) (void)rccl_api()->CommDestroy(s->comm);
+    delete s;
+    return SLAMK_OK;
+}
+
+int slamk_sharded_dims(slamk_sharded* s, int* n, int* m, int* rows_per_rank, int* srows_per_rank, int* n_padded, int* m_padded)
+{
+    if (!s || !s->P) return SLAMK_EINVAL;
+    if (n) *n = s->n; if (m) *m = s->m; if (rows_per_rank) *rows_per_rank = s->bn; if (srows_per_rank) *srows_per_rank = s->bm;
+    if (n_padded) *n_padded = s->N; if (m_padded) *m_padded = s->M;
+    return SLAMK_OK;
+}
+
+int slamk_sharded_load_cov_dev(slamk_sharded* s, const double* P_full_dev, int ld, void* stream)
+{
+    if (!s || !P_full_dev) return SLAMK_EINVAL;
+    slamk_handle* h = s->h;
+    ENTER(h);
+    note_stream(h, stream);
+    hipStream_t st = (hipStream_t)stream;
+    const int n = 9 + 3 * h->hf[0].nf, m = h->hf[0].m(), g = s->world;
+    if (ld < n) return fail(h, SLAMK_EINVAL, "sharded_load_cov: ld < n");
+    HIPCHK(h, hipStreamSynchronize(st));
+    sharded_free(s);
+    s->n = n; s->m = m;
+    s->bn = pad16((pad16(n) + g - 1) / g); s->bm = pad16((pad16(m) + g - 1) / g);
+    s->N = s->bn * g; s->M = s->bm * g;
+    s->r0 = s->rank * s->bn; s->q0 = s->rank * s->bm;
+    const size_t N = s->N, M = s->M, bn = s->bn;
+    auto alloc = [&](double** p, size_t count) -> int {
+        void* q = nullptr;
+        HIPCHK(h, hipMalloc(&q, count * sizeof(double)));
+        HIPCHK(h, hipMemsetAsync(q, 0, count * sizeof(double), st));
+        s->allocs.push_back(q);
+        *p = static_cast<double*>(q);
+        return 0;
+    };
+    int rc = 0;
+    rc |= alloc(&s->P, bn * N); rc |= alloc(&s->G1, N * N); rc |= alloc(&s->G2, N * N); rc |= alloc(&s->Ar, bn * N);
+    rc |= alloc(&s->AP, bn * N); rc |= alloc(&s->W, N * M); rc |= alloc(&s->K, N * M); rc |= alloc(&s->Y, bn * M);
+    rc |= alloc(&s->KR, bn * M); rc |= alloc(&s->S, M * M); rc |= alloc(&s->Lm, M * M); rc |= alloc(&s->Li, M * M);
+    rc |= alloc(&s->rfull, M);
+    if (rc) { sharded_free(s); return SLAMK_EHIP; }
+    const int hi = std::min(n, s->r0 + s->bn);
+    if (hi > s->r0)
+        HIPCHK(h, hipMemcpy2DAsync(s->P, N * sizeof(double), P_full_dev + (size_t)s->r0 * ld, (size_t)ld * sizeof(double),
+                                   (size_t)n * sizeof(double), hi - s->r0, hipMemcpyDeviceToDevice, st));
+    return SLAMK_OK;
+}
+
+int slamk_sharded_predict_dev(slamk_sharded* s, const double* qbw_dev, const double* w_dev, const double* acc_dev,
+                              const double* dt_dev, void* stream)
+{
+    { int rc = sharded_check(s); if (rc) return rc; }
+    slamk_handle* h = s->h;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = slamk_stage_motion_dev(h, qbw_dev, w_dev, acc_dev, dt_dev, stream);
+    if (!rc) rc = slamk_stage_right_dev(h, 0, s->P, s->N, s->bn, s->G1 + (size_t)s->r0 * s->N, s->N, stream);   // T_r = P_r F^T
+    if (!rc) { ENTER(h); rc = sharded_allgather(s, s->G1, (size_t)s->bn * s->N, st); }
+    if (!rc) rc = slamk_stage_left_dev(h, 0, s->r0, s->bn, s->G1, s->N, s->N, s->P, s->N, 1, stream);          // P_r = F_r T + Q_r
+    return rc;
+}
+
+int slamk_sharded_update_dev(slamk_sharded* s, const double* qbw_dev, const double* alt_dev, const double* src_dev,
+                             const double* refl_dev, int32_t* applied_dev, void* stream)
+{
+    { int rc = sharded_check(s); if (rc) return rc; }
+    slamk_handle* h = s->h;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t N = s->N, M = s->M, bn = s->bn, bm = s->bm, r0 = s->r0, q0 = s->q0;
+    int rc = slamk_stage_measure_dev(h, qbw_dev, alt_dev, src_dev, refl_dev, stream);
+    if (rc) return rc;
+    ENTER(h);
+    rc = slamk_stage_right_dev(h, 1, s->P, s->N, s->bn, s->W + r0 * M, s->M, stream);                          // W_r = P_r H^T
+    if (!rc) rc = sharded_allgather(s, s->W, bn * M, st);
+    if (!rc) rc = slamk_stage_left_dev(h, 1, s->q0, s->bm, s->W, s->M, s->M, s->S + q0 * M, s->M, 1, stream);  // S_q = H_q W + R_q
+    if (rc) return rc;
+    // diagonal of R over the padded measurement rows: the operator's own rows, 1 beyond them
+    const int ml = std::min(max_ml(h), s->M);
+    hipLaunchKernelGGL(fill_kernel, dim3((s->M + 255) / 256), dim3(256), 0, st, s->rfull, s->M, 1.0);
+    HIPCHK(h, hipMemcpyAsync(s->rfull, h->fv.rdiag, (size_t)ml * sizeof(double), hipMemcpyDeviceToDevice, st));
+    const int lo = std::max(s->q0, ml), hi = s->q0 + s->bm;
+    if (lo < hi)
+        hipLaunchKernelGGL(pad_identity_rows_kernel, dim3((s->M + 255) / 256, hi - lo), dim3(256), 0, st, s->S, s->M, lo, hi);
+    HIPCHK(h, hipGetLastError());
+    rc = sharded_allgather(s, s->S, bm * M, st);
+    if (rc) return rc;
+    // S = L L^T and the inverses of L's diagonal blocks, on every rank (S is scratch afterwards)
+    HIPCHK(h, hipMemsetAsync(s->Lm, 0, M * M * sizeof(double), st));
+    HIPCHK(h, hipMemsetAsync(s->Li, 0, M * M * sizeof(double), st));
+    rc = cholesky_inverse(h, s->S, s->Lm, s->Li, s->M, 0, 1, s->M, h->fv.status, st);
+    if (!rc) rc = slamk_stage_gain_dev(h, s->W + r0 * M, s->bn, s->M, s->M, s->Lm, s->Li, s->M, s->Y, s->K + r0 * M, s->KR,
+                                       s->rfull, stream);                                                      // K_r, K_r R
+    if (!rc) rc = sharded_allgather(s, s->K, bn * M, st);
+    if (!rc) rc = slamk_stage_eye_minus_kh_dev(h, s->K + r0 * M, s->M, s->r0, s->bn, s->Ar, s->N, stream);      // A_r = I_r - K_r H
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(s->G2 + r0 * N, s->Ar, bn * N * sizeof(double), hipMemcpyDeviceToDevice, st));
+    rc = sharded_allgather(s, s->G2, bn * N, st);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(s->G1 + r0 * N, s->P, bn * N * sizeof(double), hipMemcpyDeviceToDevice, st));
+    rc = sharded_allgather(s, s->G1, bn * N, st);
+    if (rc) return rc;
+    // P_r <- (A_r P) A^T + (K_r R) K^T
+    HIPCHK(h, (launch_gemm<false, EPI_NONE, false, TRI_NONE>(gargs(s->Ar, s->N, 0, s->G1, s->N, 0, s->AP, s->N, 0, s->bn, s->N, s->N), 1, st)));
+    HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_NONE>(gargs(s->AP, s->N, 0, s->G2, s->N, 0, s->P, s->N, 0, s->bn, s->N, s->N), 1, st)));
+    HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_NONE>(gargs(s->KR, s->M, 0, s->K, s->M, 0, s->P, s->N, 0, s->bn, s->N, s->M, 1.0, 1.0), 1, st)));
+    return slamk_stage_apply_dev(h, s->K, s->M, applied_dev, stream);                                           // dx = K e, gate
+}
+
+int slamk_sharded_gather_cov_dev(slamk_sharded* s, double* P_full_dev, int ld, void* stream)
+{
+    { int rc = sharded_check(s); if (rc) return rc; }
+    if (!P_full_dev || ld < s->n) return SLAMK_EINVAL;
+    slamk_handle* h = s->h;
+    ENTER(h);
+    note_stream(h, stream);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t N = s->N, bn = s->bn;
+    HIPCHK(h, hipMemcpyAsync(s->G1 + (size_t)s->r0 * N, s->P, bn * N * sizeof(double), hipMemcpyDeviceToDevice, st));
+    int rc = sharded_allgather(s, s->G1, bn * N, st);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpy2DAsync(P_full_dev, (size_t)ld * sizeof(double), s->G1, N * sizeof(double), (size_t)s->n * sizeof(double),
+                               s->n, hipMemcpyDeviceToDevice, st));
+    return SLAMK_OK;
 }
 
 // ---- stream pre-processing filters, batched --------------------------------------------------------------

@@ -18,9 +18,10 @@ block and the only traffic is one all-gather per dense contraction:
 which restates `calcP`, `calcK`, `updateP` (Joseph form) and the gated mean update of the reference
 (src/slam/main.cpp:526-530, 539-552, 561-569, 228-232) for a row-distributed P.
 
-The numerical work goes through a backend object.  `HipBackend` (the product path) drives
-libslamk.so through the C ABI and fails without a GPU; tests inject a CPU backend to exercise the
-sharding and the collectives under `gloo`.
+`ShardedFilter` is the product path: the sequence above inside libslamk.so (slamk_sharded_*, RCCL all-gathers on the
+caller's stream), which fails without a GPU.  `ShardedLargeMapFilter` is the same sequence written out over a backend
+object and `torch.distributed`: tests inject a CPU backend to rehearse the sharding and the collectives with several
+ranks under `gloo`, where no GPU exists.
 """
 import ctypes as C
 
@@ -31,108 +32,118 @@ def _pad16(x):
     return (x + 15) // 16 * 16
 
 
-class HipBackend:
-    """Local operations on the GPU through include/slamk.h (filter 0 of a FilterBatch)."""
+class ShardedFilter:
+    """The product path: row-block sharded filter behind the C ABI (slamk_sharded_* in include/slamk.h).
 
-    F, H = 0, 1
+    The orchestration and the collectives (RCCL all-gathers on the caller's stream) live in libslamk.so; this class
+    creates the communicator (the id is made on rank 0 and broadcast through torch.distributed) and forwards
+    device pointers.  With a process group that has no device collectives (gloo: rehearsals with several ranks on
+    one GPU) the library is given an all-gather callback that stages through host memory instead.
+    `fb` is a FilterBatch with batch 1 that every rank feeds with the same frames (the O(nf) state is replicated).
+    """
 
-    def __init__(self, fb, device, stream=None):
+    def __init__(self, fb, rank=0, world=1, group=None, device=None, stream=None, rccl_single_rank=False):
         from . import _lib
-        self.fb, self.L, self.device = fb, _lib.lib(), device
-        self.stream = stream if stream is not None else torch.cuda.current_stream(device)
+        self.fb, self.L, self.rank, self.world, self.group = fb, _lib.lib(), rank, world, group
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self.s = C.c_void_p()
+        self._cb = None
+        nccl_id, cb = None, None
+        if world == 1 and rccl_single_rank:      # a one-rank RCCL communicator: the collective calls are really made
+            nccl_id = (C.c_ubyte * 128)()
+            if self.L.slamk_nccl_unique_id(nccl_id):
+                raise RuntimeError("slamk_nccl_unique_id failed")
+        if world > 1:
+            import torch.distributed as dist
+            if dist.get_backend(group) == "nccl":
+                idbuf = torch.zeros(128, dtype=torch.uint8)
+                if rank == 0:
+                    raw = (C.c_ubyte * 128)()
+                    if self.L.slamk_nccl_unique_id(raw):
+                        raise RuntimeError("slamk_nccl_unique_id failed")
+                    idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+                idbuf = idbuf.to(self.device)
+                dist.broadcast(idbuf, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                nccl_id = (C.c_ubyte * 128)(*idbuf.cpu().tolist())
+            else:
+                AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
+
+                def gather(ctx, buf, bytes_per_rank, rk, wd, strm):
+                    try:
+                        class _I:
+                            pass
+                        o = _I()
+                        o.__cuda_array_interface__ = {"shape": (wd * bytes_per_rank,), "typestr": "|u1", "data": (buf, False),
+                                                      "version": 2, "strides": None}
+                        full = torch.as_tensor(o, device=self.device)
+                        self.stream.synchronize()
+                        mine = full[rk * bytes_per_rank:(rk + 1) * bytes_per_rank].cpu()
+                        host = torch.empty(wd * bytes_per_rank, dtype=torch.uint8)
+                        dist.all_gather_into_tensor(host, mine, group=self.group)
+                        with torch.cuda.stream(self.stream):
+                            full.copy_(host)
+                        self.stream.synchronize()
+                        return 0
+                    except Exception:            # never let an exception cross the C boundary
+                        import traceback
+                        traceback.print_exc()
+                        return 1
+                cb = AG(gather)
+                self._cb = cb
+        rc = self.L.slamk_sharded_create(self.fb.h, rank, world, nccl_id, C.cast(cb, C.c_void_p) if cb else None, None,
+                                         C.byref(self.s))
+        self.fb._chk(rc)
 
     @property
     def sptr(self):
         return self.stream.cuda_stream
 
-    def dims(self):
-        return 9 + 3 * self.fb.num_features(0), self.fb.num_rows(0)
+    def close(self):
+        if getattr(self, "s", None):
+            self.L.slamk_sharded_destroy(self.s)
+            self.s = None
 
-    def empty(self, rows, cols):
-        return torch.zeros((rows, cols), dtype=torch.float64, device=self.device)
-
-    def _buf(self, which):
-        ptr, r, c, ld = C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
-        self.fb._chk(self.L.slamk_buffer_dev(self.fb.h, which, C.byref(ptr), C.byref(r), C.byref(c), C.byref(ld)))
-
-        class _Iface:
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
             pass
-        o = _Iface()
-        rows = max(r.value, 1)
-        o.__cuda_array_interface__ = {"shape": (rows, ld.value), "typestr": "<f8", "data": (ptr.value, False),
-                                      "version": 2, "strides": None}
-        t = torch.as_tensor(o, device=self.device)
-        return t[:, :c.value] if r.value > 1 else t[0, :c.value]
 
-    def motion(self, qbw, w, acc, dt):
-        """Compact rows of F and diag Q at the pre-predict state, then mu += dynamics(mu) dt.  Returns diag Q."""
-        self.fb._chk(self.L.slamk_stage_motion_dev(self.fb.h, qbw.data_ptr(), w.data_ptr(), acc.data_ptr(),
-                                                   dt.data_ptr(), self.sptr))
-        return self._buf(4)
+    def dims(self):
+        v = [C.c_int() for _ in range(6)]
+        self.fb._chk(self.L.slamk_sharded_dims(self.s, *[C.byref(x) for x in v]))
+        return dict(zip(("n", "m", "rows_per_rank", "srows_per_rank", "n_padded", "m_padded"), (x.value for x in v)))
 
-    def measure(self, qbw, src=None, refl=None):
-        """Compact rows of H, innovation e and diag R."""
-        self.fb._chk(self.L.slamk_stage_measure_dev(self.fb.h, qbw.data_ptr(), None,
-                                                    None if src is None else src.data_ptr(),
-                                                    None if refl is None else refl.data_ptr(), self.sptr))
-        return self._buf(2), self._buf(3)
+    def load_cov(self, P_full):
+        """Distribute a full n x n covariance (device tensor, the same on every rank)."""
+        assert P_full.is_cuda and P_full.stride(1) == 1
+        self.fb._chk(self.L.slamk_sharded_load_cov_dev(self.s, P_full.data_ptr(), P_full.stride(0), self.sptr))
 
-    def right(self, which, Out, In):
-        """Out = In * M^T for a row block In (M = F or H)."""
-        assert In.stride(1) == 1 and Out.stride(1) == 1 and In.shape[0] == Out.shape[0]
-        self.fb._chk(self.L.slamk_stage_right_dev(self.fb.h, which, In.data_ptr(), In.stride(0), In.shape[0],
-                                                  Out.data_ptr(), Out.stride(0), self.sptr))
+    def predict(self, qbw, w, acc, dt):
+        self.fb._chk(self.L.slamk_sharded_predict_dev(self.s, qbw.data_ptr(), w.data_ptr(), acc.data_ptr(), dt.data_ptr(),
+                                                      self.sptr))
 
-    def left(self, which, Out, row0, In, add_diag):
-        """Out = M[row0 : row0 + rows, :] * In (+ diag Q / R on the operator's diagonal)."""
-        assert In.stride(1) == 1 and Out.stride(1) == 1 and In.shape[1] == Out.shape[1]
-        self.fb._chk(self.L.slamk_stage_left_dev(self.fb.h, which, row0, Out.shape[0], In.data_ptr(), In.stride(0),
-                                                 In.shape[1], Out.data_ptr(), Out.stride(0), int(bool(add_diag)),
-                                                 self.sptr))
-
-    def eye_minus_kh(self, A, K, row0):
-        """A = I[row0 : row0 + rows, :] - K H for the rank's rows of K."""
-        assert A.stride(1) == 1 and K.stride(1) == 1 and A.shape[0] == K.shape[0]
-        self.fb._chk(self.L.slamk_stage_eye_minus_kh_dev(self.fb.h, K.data_ptr(), K.stride(0), row0, K.shape[0],
-                                                         A.data_ptr(), A.stride(0), self.sptr))
-
-    def gain(self, Y, K, KR, W, Lm, Li, rd):
-        """K = W S^-1 (two block triangular solves with L and its diagonal-block inverses Li), KR = K diag(rd), for
-        the rank's rows of W; W is overwritten, Y is workspace."""
-        m = Li.shape[0]
-        assert W.stride(0) == Y.stride(0) == K.stride(0) == KR.stride(0) and rd.shape[0] >= m
-        self.fb._chk(self.L.slamk_stage_gain_dev(self.fb.h, W.data_ptr(), W.shape[0], m, W.stride(0), Lm.data_ptr(), Li.data_ptr(),
-                                                 Li.stride(0), Y.data_ptr(), K.data_ptr(), KR.data_ptr(),
-                                                 rd.data_ptr(), self.sptr))
-
-    def gemm(self, Cm, A, Bm, trans_b, alpha=1.0, beta=0.0):
-        """Cm = alpha * A * op(Bm) + beta * Cm on row-major views with unit inner stride."""
-        M, K = A.shape
-        N = Cm.shape[1]
-        assert A.stride(1) == 1 and Bm.stride(1) == 1 and Cm.stride(1) == 1
-        assert M % 16 == 0 and N % 16 == 0 and K % 16 == 0, (M, N, K)
-        rc = self.L.slamk_dgemm_dev(int(bool(trans_b)), M, N, K, alpha, A.data_ptr(), A.stride(0), 0, Bm.data_ptr(),
-                                    Bm.stride(0), 0, beta, Cm.data_ptr(), Cm.stride(0), 0, 1, self.sptr)
-        if rc:
-            raise RuntimeError("slamk_dgemm_dev failed: %d" % rc)
-
-    def cholesky_inverse(self, S, Lm, Li):
-        rc = self.L.slamk_cholesky_inverse_dev(S.data_ptr(), Lm.data_ptr(), Li.data_ptr(), S.shape[0], S.stride(0),
-                                               None, self.sptr)
-        if rc:
-            raise RuntimeError("slamk_cholesky_inverse_dev failed: %d" % rc)
-
-    def apply(self, K):
+    def update(self, qbw, src=None, refl=None):
         applied = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self.fb._chk(self.L.slamk_stage_apply_dev(self.fb.h, K.data_ptr(), K.stride(0), applied.data_ptr(), self.sptr))
+        self.fb._chk(self.L.slamk_sharded_update_dev(self.s, qbw.data_ptr(), None,
+                                                     None if src is None else src.data_ptr(),
+                                                     None if refl is None else refl.data_ptr(), applied.data_ptr(), self.sptr))
         return applied
 
+    def gather_cov(self):
+        n = 9 + 3 * self.fb.num_features(0)
+        out = torch.zeros((n, n), dtype=torch.float64, device=self.device)
+        self.fb._chk(self.L.slamk_sharded_gather_cov_dev(self.s, out.data_ptr(), n, self.sptr))
+        return out
+
     def sync(self):
-        self.stream.synchronize()
+        self.fb.sync(self.sptr)
 
 
 class ShardedLargeMapFilter:
-    """Covariance of one filter sharded by row blocks over `world` ranks (see module docstring)."""
+    """The sequence of the module docstring over a backend object (CPU rehearsal of the sharding; the product path is
+    ShardedFilter)."""
 
     F, H = 0, 1
 

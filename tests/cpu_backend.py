@@ -1,4 +1,4 @@
-"""CPU stand-in for slam_amd.sharded.HipBackend (TEST INFRASTRUCTURE): the local operations of the
+"""CPU backend of slam_amd.sharded.ShardedLargeMapFilter (TEST INFRASTRUCTURE): the local operations of the
 row-block sharded filter done with the oracle and torch CPU tensors, so that the sharding logic and
 the collectives can run under gloo without a GPU."""
 import numpy as np

@@ -572,84 +572,85 @@ def test_full_size_batch_properties():
         assert np.linalg.eigvalsh(P).min() > 0
 
 
-def test_sharded_filter_hip_backend_single_rank():
-    """slam_amd/sharded.py with its HIP backend (world = 1: same products and stage calls as with
-    more ranks, no collective) against the oracle."""
-    torch = _torch()
-    from slam_amd.sharded import HipBackend, ShardedLargeMapFilter
-    nf, steps = 45, 7
+def _run_sharded(rank, world, group, nf, steps, dev, rccl_single_rank=False):
+    """The stream of the sharded tests through slamk_sharded_* on this rank; returns (P, state vector)."""
+    import torch
+    from slam_amd.sharded import ShardedFilter
     st = synth.gen_stream(seed=17, nf=nf, steps=steps, churn=False)
-    so, f = helpers.run_oracle(st)
     inp = helpers.stream_inputs(st, 7)
-    dev = torch.device("cuda", 0)
     fb = ekf.FilterBatch(max_features=nf, batch=1)
     fb.set_state(0, X=st.init_pos)
     fb.frame(0, inp[0][5], inp[0][1])
-    be = HipBackend(fb, dev)
-    sh = ShardedLargeMapFilter(be, 0, 1)
-    sh.load_cov(torch.from_numpy(fb.get_cov(0)).to(dev))
+    stream = torch.cuda.Stream(device=dev)
+    sh = ShardedFilter(fb, rank, world, group, device=dev, stream=stream, rccl_single_rank=rccl_single_rank)
+    P0 = torch.from_numpy(fb.get_cov(0)).to(dev)
+    torch.cuda.synchronize()
+    sh.load_cov(P0)
     t = lambda v: torch.tensor(np.asarray(v, dtype=np.float64), device=dev)
+    applied = []
     for k in range(1, steps):
         u, quat, ang, acc, dt, matches = inp[k]
         if u & orc.IMG:
             fb.frame(0, matches, quat)
-        sh.predict(t(quat), t(ang), t(acc), t([dt]))
+        q, w, a, d = t(quat), t(ang), t(acc), t([dt])
+        torch.cuda.synchronize()
+        sh.predict(q, w, a, d)
         if u & orc.IMG:
-            applied = sh.update(t(quat))
-            be.sync()
-            assert int(applied.item()) == so[k - 1]["applied"]
-    be.sync()
-    P = sh.gather_cov().cpu().numpy()
-    assert helpers.rel_err(P, f.P) < TOL
-    assert helpers.rel_err(fb.state_vector(0), f.state_vector()) < TOL
+            ap = sh.update(q)
+            sh.sync()
+            applied.append(int(ap.item()))
+    P = sh.gather_cov()
+    sh.sync()
+    out = P.cpu().numpy(), fb.state_vector(0), applied, sh.dims()
+    sh.close()
+    fb.close()
+    return out
 
 
-def _sharded_hip_worker(rank, world, port, nf, steps, out):
+@pytest.mark.parametrize("rccl", [False, True])
+def test_sharded_filter_single_rank(rccl):
+    """slamk_sharded_* with one rank (the same products and stage calls as with more ranks) against the oracle; with
+    `rccl` the library builds a one-rank RCCL communicator and its all-gathers really go through ncclAllGather."""
+    torch = _torch()
+    nf, steps = 45, 7
+    st = synth.gen_stream(seed=17, nf=nf, steps=steps, churn=False)
+    so, f = helpers.run_oracle(st)
+    P, sv, applied, dims = _run_sharded(0, 1, None, nf, steps, torch.device("cuda", 0), rccl_single_rank=rccl)
+    assert applied == [s["applied"] for s in so if s["applied"] >= 0]
+    assert helpers.rel_err(P, f.P) < TOL and helpers.entry_err(P, f.P) < TOL
+    assert helpers.rel_err(sv, f.state_vector()) < TOL
+    assert dims["n"] == 9 + 3 * nf and dims["rows_per_rank"] == dims["n_padded"]
+
+
+def _sharded_worker(rank, world, port, nf, steps, out):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from slam_amd.sharded import HipBackend, ShardedLargeMapFilter
-        st = synth.gen_stream(seed=17, nf=nf, steps=steps, churn=False)
-        inp = helpers.stream_inputs(st, 7)
-        dev = torch.device("cuda", 0)
-        fb = ekf.FilterBatch(max_features=nf, batch=1)
-        fb.set_state(0, X=st.init_pos)
-        fb.frame(0, inp[0][5], inp[0][1])
-        be = HipBackend(fb, dev)
-        sh = ShardedLargeMapFilter(be, rank, world)
-        sh.load_cov(torch.from_numpy(fb.get_cov(0)).to(dev))
-        t = lambda v: torch.tensor(np.asarray(v, dtype=np.float64), device=dev)
-        for k in range(1, steps):
-            u, quat, ang, acc, dt, matches = inp[k]
-            if u & orc.IMG:
-                fb.frame(0, matches, quat)
-            sh.predict(t(quat), t(ang), t(acc), t([dt]))
-            if u & orc.IMG:
-                sh.update(t(quat))
-        be.sync()
-        P = sh.gather_cov().cpu().numpy()
-        if rank == 0:
-            np.save(out, np.concatenate([P.ravel(), fb.state_vector(0)]))
-        fb.close()
+        P, sv, applied, dims = _run_sharded(rank, world, None, nf, steps, torch.device("cuda", 0))
+        assert dims["rows_per_rank"] * world == dims["n_padded"]
+        if rank == world - 1:
+            np.save(out, np.concatenate([P.ravel(), sv]))
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_filter_hip_backend_two_ranks_on_one_gpu(tmp_path):
-    """Two ranks of the sharded filter, both on GPU 0, all-gathers rehearsed over gloo (staged through the host):
-    the row-block stage calls with row0 > 0 against the oracle."""
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_filter_several_ranks_on_one_gpu(tmp_path, world):
+    """Two and three ranks of slamk_sharded_*, all on GPU 0, the library's all-gathers routed through its callback
+    (gloo, staged through the host): row blocks with row0 > 0, padding rows in the last block, against the oracle."""
     import socket
     import torch.multiprocessing as mp
-    nf, steps, world = 45, 7, 2
+    nf, steps = 45, 7
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     out = str(tmp_path / "res.npy")
-    mp.spawn(_sharded_hip_worker, args=(world, port, nf, steps, out), nprocs=world, join=True)
+    mp.spawn(_sharded_worker, args=(world, port, nf, steps, out), nprocs=world, join=True)
     res = np.load(out)
     st = synth.gen_stream(seed=17, nf=nf, steps=steps, churn=False)
     so, f = helpers.run_oracle(st)
     n = 9 + 3 * nf
     assert helpers.rel_err(res[:n * n].reshape(n, n), f.P) < TOL
+    assert helpers.entry_err(res[:n * n].reshape(n, n), f.P) < TOL
     assert helpers.rel_err(res[n * n:], f.state_vector()) < TOL
