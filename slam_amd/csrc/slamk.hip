@@ -651,9 +651,13 @@ bool fuse_apply(int B) { return B <= 256; }
 template <int NT>
 int launch_joseph(slamk_handle* h, const Range& rg, int ml, int* applied, hipStream_t st)
 {
-    const size_t lds = (size_t)(NT * NT + (NT <= 7 ? 2 : 1) * NT + 2) * 256 * sizeof(double);
-    { int rc_ = ensure_dynamic_lds(h, reinterpret_cast<const void*>(joseph_kernel<NT>), lds); if (rc_) return rc_; }
-    hipLaunchKernelGGL(joseph_kernel<NT>, dim3(rg.B), dim3(512), lds, st, rg.fv, rg.K, h->ldm,
+    // up to n = 112 the variant that reads K once (its tables hold 256 measurement rows: n <= 112 has m <= 205)
+    constexpr bool MERGED = NT <= 7;
+    const size_t lds = (size_t)(NT * NT + (MERGED ? 2 * NT + 10 : NT + 2)) * 256 * sizeof(double);
+    auto kern = [] { if constexpr (MERGED) return joseph_merged_kernel<NT>; else return joseph_kernel<NT>; }();
+    if (MERGED && ml > 256) return fail(h, SLAMK_EINVAL, "fused covariance update: %d measurement rows for n <= %d", ml, 16 * NT);
+    { int rc_ = ensure_dynamic_lds(h, reinterpret_cast<const void*>(kern), lds); if (rc_) return rc_; }
+    hipLaunchKernelGGL(kern, dim3(rg.B), dim3(512), lds, st, rg.fv, rg.K, h->ldm,
                        (long long)h->ldn * h->ldm, ml, h->prm.update_form, fuse_apply(rg.B) ? (double*)nullptr : rg.dx,
                        fuse_apply(rg.B) ? 1 : 0, applied);
     HIPCHK(h, hipGetLastError());
