@@ -209,11 +209,13 @@ def single_filter_latency(torch, dev, nf=20, iters=40):
             "latency_us_per_update": t * 1e6, "latency_us_iteration_only": t_iter * 1e6}
 
 
-def sweep_point(torch, dev, nf, B, iters=6):
+def sweep_point(torch, dev, nf, B, iters=6, form=0):
     """Updates/s at another (state dim, batch) point: same step as the headline workload, groups = 1."""
     from slam_amd import ekf
     st, steps = build_inputs(torch, dev, B, nf, iters + 2, 0)
-    fb = ekf.FilterBatch(max_features=nf, batch=B, device=dev.index or 0)
+    prm = ekf.default_params()
+    prm.update_form = form
+    fb = ekf.FilterBatch(max_features=nf, batch=B, device=dev.index or 0, params=prm)
     for b in range(B):
         fb.set_state(b, X=st.init_pos)
     fb.frame(-1, first_frame(st), st.steps[0].quat)
@@ -230,8 +232,11 @@ def sweep_point(torch, dev, nf, B, iters=6):
     fb.sync(s0.cuda_stream)
     t = (time.perf_counter() - t0) / iters
     n, m = 9 + 3 * nf, fb.num_rows(0)
+    P = fb.get_cov(B // 2)
+    sane = bool(np.all(np.isfinite(P)) and np.all(np.diag(P)[:n] > 0))
     fb.close()
-    return {"features": nf, "state_dim": n, "meas_dim": m, "batch": B, "updates_per_s": B / t, "ms_per_step": t * 1e3}
+    return {"features": nf, "state_dim": n, "meas_dim": m, "batch": B, "updates_per_s": B / t, "ms_per_step": t * 1e3,
+            "cov_sane": sane}
 
 
 def large_map(torch, dev, nf=2000, iters=2):

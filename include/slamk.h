@@ -62,7 +62,13 @@ typedef struct {
     double gate, d_min, d_max, dinit;
     /* 0: gain by Cholesky of S, covariance by the Joseph form (I-KH)P(I-KH)^T + K R K^T.
      * 1: gain by Cholesky of S, covariance as the reference writes it, (I-KH)P then (P+P^T)/2
-     *    (src/slam/main.cpp:561-569).  Both equal the reference's LU form up to rounding. */
+     *    (src/slam/main.cpp:561-569).  Both equal the reference's LU form up to rounding.
+     * 2: block-sequential update, n <= 160 only (SLAMK_EINVAL beyond): the measurement rows are processed 16 at
+     *    a time against the covariance held on chip (W_c = P H_c^T, S_c = H_c W_c + R_c, K_c = W_c S_c^-1,
+     *    P -= K_c W_c^T, dx += K_c (e_c - H_c dx)).  R is diagonal and H fixed during an update, so posterior
+     *    and total correction dx = K e are those of forms 0 and 1 up to rounding; the gate uses the total dx.
+     *    It is not the reference's sequence of operations (one m x m system) and is therefore not the default;
+     *    slamk_debug_get has no K or L to return in this form. */
     int32_t update_form;
 } slamk_params;
 

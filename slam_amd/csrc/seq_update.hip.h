@@ -1,0 +1,217 @@
+// Block-sequential measurement update for filters whose covariance fits LDS (update_form = 2), one workgroup per
+// filter.  R is diagonal (initR, src/slam/main.cpp:449-476) and H is fixed during an update, so processing the
+// measurement rows 16 at a time,
+//     W_c = P H_c^T,  S_c = H_c W_c + R_c = L_c L_c^T,  K_c = W_c S_c^-1,  P <- P - K_c W_c^T,
+//     dx <- dx + K_c (e_c - H_c dx),
+// gives the same posterior covariance and the same total correction dx = K e as one gain for the whole measurement
+// vector (calcK / updateP / K * eeMat, src/slam/main.cpp:221-228) in exact arithmetic; the gate and the mean update
+// (:229-232) use the total dx as there.  It is NOT the reference's sequence of operations (one m x m system), so it
+// is an option beside the default, held to the same tolerance.  Work per update: ~ (NT (NT + 1) / 2 + 2 NT) tile
+// products per chunk instead of an m x m factorisation, two n x m triangular solves and three n x n products;
+// neither S nor K ever exists in memory, and P is read and written once.
+//
+// LDS: the lower tiles of P (NT (NT + 1) / 2, tile (I, J), I >= J, at tile_index(I, J); symmetric reads go through the
+// transposed tile), the panels W_c and K_c (NT tiles each), inv(L_c), the chunk's compact rows of H (two buffers).
+// n <= 160 (NT <= 10): 79 tiles.  Per chunk four barriers: W_c and e' -> S_c, factor, inverse (one wavefront, in
+// registers) -> K_c -> P and dx.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gain_solver.hip.h"
+
+namespace slamk {
+
+template <int NT>
+struct SeqUpdateLds {
+    static constexpr int TILES = NT * (NT + 1) / 2 + 2 * NT + 4;
+};
+
+template <int NT>
+__global__ void __launch_bounds__(512) seq_update_kernel(FilterView fv, double* __restrict__ dx, int apply,
+                                                          int* __restrict__ applied)
+{
+    extern __shared__ double lds[];
+    constexpr int NL = 16 * NT, NPT = NT * (NT + 1) / 2;
+    double* wp = lds + NPT * 256;                        // W_c: NT tiles, rows = states, 16 columns
+    double* kp = wp + NT * 256;                          // K_c, same shape
+    double* linv = kp + NT * 256;                        // inv(L_c)
+    double* tab = linv + 256;                            // [2][16][8]: ha[3], hb[3], e, r of the chunk's rows
+    double* dxs = tab + 256;                             // [NL]
+    double* ev = dxs + NL;                               // [16] e_c - H_c dx
+    int* tcs = reinterpret_cast<int*>(ev + 16);          // [2][16] first column of the feature entries (-1: none)
+    static_assert(256 + NL + 16 + 16 <= 3 * 256, "LDS layout");
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int ldn = fv.ldn;
+    double* Pb = fv.P + (long long)b * ldn * ldn;
+    const long long rb = (long long)b * fv.ldm;
+    const int nf = fv.nf[b];
+    const int m = fv.m[b];
+    const int nchunk = (m + 15) / 16;                    // rows m .. 16 nchunk - 1: H = 0, e = 0, r = 1 (measure_kernel)
+
+    auto psym = [&](int a, int c) -> double {            // P[a][c] from the lower tiles
+        const int I = a >> 4, J = c >> 4;
+        return I >= J ? lds[tile_index(I, J) * 256 + tsw(a & 15, c & 15)] : lds[tile_index(J, I) * 256 + tsw(c & 15, a & 15)];
+    };
+    // table rows of a chunk: one thread per row
+    double trow[8];
+    int tc = -1;
+    auto request_rows = [&](int c) {
+        if (tid < 16) {
+            const long long q = rb + 16 * c + tid;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { trow[k] = fv.ha[q * 3 + k]; trow[3 + k] = fv.hb[q * 3 + k]; }
+            trow[6] = fv.e[q]; trow[7] = fv.rdiag[q];
+            tc = fv.hcs[q];
+        }
+    };
+    auto store_rows = [&](int buf) {
+        if (tid < 16) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tab[(buf * 16 + tid) * 8 + k] = trow[k];
+            tcs[buf * 16 + tid] = tc;
+        }
+    };
+    if (nchunk > 0) request_rows(0);
+    for (int t = wave; t < NPT; t += 8) {                // lower tiles of P
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= t) ++I;
+        const int J = t - I * (I + 1) / 2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            lds[t * 256 + tsw(lk + 4 * r, li)] = Pb[(long long)(16 * I + lk + 4 * r) * ldn + 16 * J + li];
+    }
+    if (tid < NL) dxs[tid] = 0.0;
+    store_rows(0);
+    __syncthreads();
+
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        const double* tb = tab + buf * 128;
+        const int* cs = tcs + buf * 16;
+        if (c + 1 < nchunk) request_rows(c + 1);
+        // ---- W_c = P H_c^T and e' = e_c - H_c dx ----------------------------------------------------------------------
+        for (int idx = tid; idx < NL * 16; idx += 512) {
+            const int a = idx >> 4, k = idx & 15;
+            const double* h = tb + 8 * k;
+            const int c0 = max(cs[k], 0);                // (no feature entries: hb = 0)
+            double w = psym(a, 0) * h[0];
+            w = fma(psym(a, 1), h[1], w);
+            w = fma(psym(a, 2), h[2], w);
+            w = fma(psym(a, c0), h[3], w);
+            w = fma(psym(a, c0 + 1), h[4], w);
+            w = fma(psym(a, c0 + 2), h[5], w);
+            wp[(a >> 4) * 256 + tsw(a & 15, k)] = w;
+        }
+        if (tid >= 448 && tid < 464) {                   // (a wavefront with the fewest elements above)
+            const int k = tid - 448;
+            const double* h = tb + 8 * k;
+            const int c0 = max(cs[k], 0);
+            double v = h[6];
+            v = fma(-h[0], dxs[0], v); v = fma(-h[1], dxs[1], v); v = fma(-h[2], dxs[2], v);
+            v = fma(-h[3], dxs[c0], v); v = fma(-h[4], dxs[c0 + 1], v); v = fma(-h[5], dxs[c0 + 2], v);
+            ev[k] = v;
+        }
+        __syncthreads();
+        // ---- S_c = H_c W_c + R_c in accumulator layout, factor, inverse: one wavefront, registers --------------------
+        if (wave == 0) {
+            v4d s;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = lk + 4 * r;                // row of S_c, column li
+                const double* h = tb + 8 * q;
+                const int c0 = max(cs[q], 0);
+                double v = h[0] * wp[tsw(0, li)];
+                v = fma(h[1], wp[tsw(1, li)], v);
+                v = fma(h[2], wp[tsw(2, li)], v);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int a = c0 + k;
+                    v = fma(h[3 + k], wp[(a >> 4) * 256 + tsw(a & 15, li)], v);
+                }
+                s[r] = v + (q == li ? h[7] : 0.0);
+            }
+            // S_c is symmetric up to rounding; the routine reads it as such (row li of a pivot column from column li)
+            diag_tile_factor_invert_acc(s, linv, nullptr, 0, lane);
+        }
+        __syncthreads();
+        // ---- K_c = W_c inv(L_c)^T inv(L_c), by row blocks: K^T = inv(L)^T (inv(L) W^T) ------------------------------
+        for (int blk = wave; blk < NT; blk += 8) {
+            v4d wt;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wt[r] = wp[blk * 256 + tsw(li, lk + 4 * r)];
+            const v4d yt = tile_mma_regB<false, false>(linv, wt, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
+            const v4d kt = tile_mma_regB<true, false>(linv, yt, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) kp[blk * 256 + tsw(li, lk + 4 * r)] = kt[r];
+        }
+        store_rows(buf ^ 1);
+        __syncthreads();
+        // ---- P <- P - K_c W_c^T on the lower tiles; dx <- dx + K_c e' ------------------------------------------------
+        for (int t = wave; t < NPT; t += 8) {
+            int I = 0;
+            while ((I + 1) * (I + 2) / 2 <= t) ++I;
+            const int J = t - I * (I + 1) / 2;
+            double* pt = lds + t * 256;
+            v4d acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = pt[tsw(lk + 4 * r, li)];
+            acc = tile_mma_ldsBt<true>(kp + I * 256, wp + J * 256, acc, li, lk);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pt[tsw(lk + 4 * r, li)] = acc[r];
+        }
+        if (tid < NL) {
+            const double* kr = kp + (tid >> 4) * 256;
+            double v = dxs[tid];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                double k4[4];
+                tile_ld4(kr, tid & 15, 4 * g, k4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v = fma(k4[k], ev[4 * g + k], v);
+            }
+            dxs[tid] = v;
+        }
+        __syncthreads();
+    }
+
+    // ---- store: every lower tile with its mirror image; diagonal tiles from their lower half -------------------------
+    if (dx && tid < NL) dx[(long long)b * ldn + tid] = dxs[tid];
+    for (int t = wave; t < NPT; t += 8) {
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= t) ++I;
+        const int J = t - I * (I + 1) / 2;
+        const double* pt = lds + t * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = lk + 4 * r;
+            const double v = pt[tsw(row, li)], vt = pt[tsw(li, row)];
+            if (I != J) {
+                Pb[(long long)(16 * I + row) * ldn + 16 * J + li] = v;             // (row, li) of the tile
+                Pb[(long long)(16 * J + row) * ldn + 16 * I + li] = vt;            // (li, row) of the tile, transposed
+            } else
+                Pb[(long long)(16 * I + row) * ldn + 16 * I + li] = row >= li ? v : vt;
+        }
+    }
+    // ---- gate on the velocity correction and mean update (src/slam/main.cpp:229-232) -----------------------------------
+    if (apply && wave == 7) {
+        const double* V = fv.V + 3 * b;
+        const bool gate_ok = fabs(V[0] - dxs[3]) + fabs(V[1] - dxs[4]) + fabs(V[2] - dxs[5]) < fv.gate;
+        if (lane == 0 && applied) applied[b] = gate_ok;
+        if (gate_ok) {
+            const double dv = lane < 3 ? dxs[3 + lane] : 0.0;      // read by every lane before any lane writes V
+            if (lane < 3) {
+                fv.X[3 * b + lane] += dxs[lane];
+                fv.V[3 * b + lane] += dv;
+            }
+            const long long fb = (long long)b * 3 * fv.F;
+            for (int t = lane; t < 3 * nf; t += 64) {
+                const int i = t / 3, cc = t - 3 * i;
+                fv.pib[fb + (long long)cc * fv.F + i] += dxs[6 + t];
+            }
+        }
+    }
+}
+
+}  // namespace slamk

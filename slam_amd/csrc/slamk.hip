@@ -23,6 +23,7 @@
 #include "linalg_kernels.hip.h"
 #include "structured_kernels.hip.h"
 #include "joseph_kernel.hip.h"
+#include "seq_update.hip.h"
 #include "preprocess_kernels.hip.h"
 #include "frame_kernels.hip.h"
 
@@ -270,6 +271,10 @@ bool use_fused_solver(int nl, int m) { return nl <= 16 * SOLVER_MAX_NT && tiled_
 // the fused covariance update only needs P in LDS (and at most 256 tiled measurement rows for its copy of diag R)
 bool use_fused_joseph(int nl, int m) { return nl <= 16 * SOLVER_MAX_NT && tiled_rows(m) <= 256; }
 
+// update_form = 2: block-sequential update for filters whose covariance (lower tiles) fits LDS
+constexpr int SEQ_MAX_NT = 10;
+bool use_seq_update(const slamk_handle* h, int nl) { return h->prm.update_form == 2 && nl <= 16 * SEQ_MAX_NT; }
+
 // Workspaces beyond P, T and K.  The per-filter fused kernels keep every intermediate in LDS, so a batch of small
 // filters never touches these: they are allocated when a layout or the debug switch first needs them.
 enum { WS_GAIN = 1,     // W, Y, KR, S, L, Li: gain by blocked Cholesky + GEMMs
@@ -280,8 +285,9 @@ int ensure_workspaces(slamk_handle* h)
 {
     const int nl = max_nl(h), mm = max_m(h);
     int need = 0;
-    if (!use_fused_solver(nl, mm)) need |= WS_GAIN;
-    if (!use_fused_joseph(nl, mm)) need |= WS_COV;
+    const bool seq = use_seq_update(h, nl);    // the block-sequential update keeps everything in LDS
+    if (!seq && !use_fused_solver(nl, mm)) need |= WS_GAIN;
+    if (!seq && !use_fused_joseph(nl, mm)) need |= WS_COV;
     if (h->debug) need |= WS_DENSE;
     need &= ~h->have_ws;
     if (!need) return 0;
@@ -680,6 +686,35 @@ int run_joseph(slamk_handle* h, const Range& rg, int nl, int ml, int* applied, h
     }
 }
 
+template <int NT>
+int launch_seq_update(slamk_handle* h, const Range& rg, int* applied, hipStream_t st)
+{
+    const size_t lds = (size_t)SeqUpdateLds<NT>::TILES * 256 * sizeof(double);
+    { int rc_ = ensure_dynamic_lds(h, reinterpret_cast<const void*>(seq_update_kernel<NT>), lds); if (rc_) return rc_; }
+    hipLaunchKernelGGL(seq_update_kernel<NT>, dim3(rg.B), dim3(512), lds, st, rg.fv, fuse_apply(rg.B) ? (double*)nullptr : rg.dx,
+                       fuse_apply(rg.B) ? 1 : 0, applied);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int run_seq_update(slamk_handle* h, const Range& rg, int nl, int* applied, hipStream_t st)
+{
+    ProfScope ps(h, PC_GEMM_COV, st);
+    switch (nl / 16) {
+        case 1: return launch_seq_update<1>(h, rg, applied, st);
+        case 2: return launch_seq_update<2>(h, rg, applied, st);
+        case 3: return launch_seq_update<3>(h, rg, applied, st);
+        case 4: return launch_seq_update<4>(h, rg, applied, st);
+        case 5: return launch_seq_update<5>(h, rg, applied, st);
+        case 6: return launch_seq_update<6>(h, rg, applied, st);
+        case 7: return launch_seq_update<7>(h, rg, applied, st);
+        case 8: return launch_seq_update<8>(h, rg, applied, st);
+        case 9: return launch_seq_update<9>(h, rg, applied, st);
+        case 10: return launch_seq_update<10>(h, rg, applied, st);
+        default: return fail(h, SLAMK_EINVAL, "block-sequential update: n = %d out of range", nl);
+    }
+}
+
 int run_update(slamk_handle* h, const Range& rg, const double* qbw, const double* alt, const double* src, const double* refl,
                int* applied, hipStream_t st)
 {
@@ -699,6 +734,19 @@ int run_update(slamk_handle* h, const Range& rg, const double* qbw, const double
         if (keep_dense(h, nl))
             hipLaunchKernelGGL(build_H_kernel, dim3((nl + 63) / 64, (ml + 3) / 4, B), dim3(256), 0, st, rg.fv, rg.Hm,
                                ml, nl);
+    }
+    if (h->prm.update_form == 2) {
+        // measurement rows 16 at a time against the covariance in LDS: gain, covariance, dx, gate in one kernel
+        if (!use_seq_update(h, nl))
+            return fail(h, SLAMK_EINVAL, "update_form 2 (block-sequential) needs n <= %d, got %d", 16 * SEQ_MAX_NT, nl);
+        int rc = run_seq_update(h, rg, nl, applied, st);
+        if (rc) return rc;
+        if (!fuse_apply(B)) {
+            ProfScope ps_tail(h, PC_FEATURE, st);
+            hipLaunchKernelGGL(gain_apply_kernel, dim3(B), dim3(256), 0, st, rg.fv, rg.dx, applied);
+        }
+        HIPCHK(h, hipGetLastError());
+        return 0;
     }
     const RowSparse MH{rg.fv.ha, rg.fv.hb, rg.fv.hcs, ldm, 0};
     {

@@ -26,7 +26,7 @@ class _S:
         self.init_pos = init_pos
 
 
-@pytest.mark.parametrize("nf,form", [(5, 0), (20, 0), (20, 1), (32, 0), (32, 1)])
+@pytest.mark.parametrize("nf,form", [(5, 0), (20, 0), (20, 1), (32, 0), (32, 1), (5, 2), (20, 2), (32, 2)])
 def test_stream_fixtures(nf, form):
     fx = helpers.FixtureStream(os.path.join(G, "stream_nf%d.npz" % nf))
     p = ekf.default_params()

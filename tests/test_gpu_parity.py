@@ -71,7 +71,7 @@ def test_dgemm_kernel_against_numpy():
     assert np.array_equal(dC.cpu().numpy(), Bm.T)
 
 
-@pytest.mark.parametrize("nf,form", [(5, 0), (20, 0), (20, 1), (32, 0), (32, 1)])
+@pytest.mark.parametrize("nf,form", [(5, 0), (20, 0), (20, 1), (32, 0), (32, 1), (5, 2), (20, 2), (32, 2)])
 def test_single_filter_stream_parity(nf, form):
     st = synth.gen_stream(seed=10 + nf, nf=nf, steps=61, churn=True, drop_at=21, drop_count=min(3, nf - 1),
                           add_at=42, add_count=3)
@@ -87,11 +87,14 @@ def test_single_filter_stream_parity(nf, form):
 
 
 @pytest.mark.parametrize("nf,ref_fraction,form", [(2, 0.5, 0), (38, 0.0, 0), (38, 0.0, 1), (26, 1.0, 0), (36, 1.0, 0),
-                                                  (13, 0.5, 0), (29, 0.5, 0), (1, 1.0, 0)])
+                                                  (13, 0.5, 0), (29, 0.5, 0), (1, 1.0, 0),
+                                                  (2, 0.5, 2), (38, 0.0, 2), (36, 1.0, 2), (13, 0.5, 2), (1, 1.0, 2),
+                                                  (50, 0.5, 2), (45, 1.0, 2)])
 def test_fused_path_tile_count_edges(nf, ref_fraction, form):
     """Smallest filter, eight 16-row blocks of the state (n = 123), all-reflection rows (m = 157), and a filter
     whose S exceeds the fused solver (m = 217) while its P still fits the fused covariance update (n = 117); state
-    dimensions that fill their tiles exactly (n = 48, 96: no padding rows); a single reflective feature."""
+    dimensions that fill their tiles exactly (n = 48, 96: no padding rows); a single reflective feature.  Form 2 (the
+    block-sequential update) at the same edges and at its own: n = 159 (ten row blocks, its limit) and m = 271."""
     st = synth.gen_stream(seed=70 + nf, nf=nf, steps=31, churn=False, ref_fraction=ref_fraction)
     so, _ = helpers.run_oracle(st)
     p = ekf.default_params()
@@ -177,7 +180,7 @@ def test_random_configurations_against_oracle():
         st = synth.gen_stream(seed=500 + case, nf=nf, steps=steps, churn=churn, ref_fraction=ref, **kw)
         so, _ = helpers.run_oracle(st)
         p = ekf.default_params()
-        p.update_form = int(rng.integers(0, 2))
+        p.update_form = int(rng.integers(0, 3))
         fb = ekf.FilterBatch(max_features=nf + 6, batch=1, params=p)
         sg = helpers.run_gpu(st, fb)
         worst = max(worst, compare_snaps(so, sg))
