@@ -13,11 +13,20 @@
 // LDS: the lower tiles of P (NT (NT + 1) / 2, tile (I, J), I >= J, at tile_index(I, J); symmetric reads go through the
 // transposed tile), the panels W_c and K_c (NT tiles each), inv(L_c), the chunk's compact rows of H (two buffers).
 // n <= 160 (NT <= 10): 79 tiles.  Per chunk four barriers: W_c and e' -> S_c, factor, inverse (one wavefront, in
-// registers) -> K_c -> P and dx.
+// registers) -> K_c -> P and dx.  Cycle stamps at 32 features (scripts/seq_bench.hip): 14k to load P, then per chunk
+// W_c 2.6k, S_c 0.9k + factorisation and inverse 4.3k (one wavefront, the others wait), K_c 1.6k, P and dx 4.9k;
+// 180k per filter.  Measured no faster: K_c kept in registers with the tiles of a row block done by the wavefront that
+// owns it (one panel and one barrier less, 76 KB of LDS so that two workgroups share a compute unit, but 1 .. NT tiles
+// per wavefront and 128 registers per lane, which the factorisation in registers does not fit), and the lower tiles
+// dealt evenly, two at a time.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include "gain_solver.hip.h"
+
+#ifndef SEQ_STAMP
+#define SEQ_STAMP(i)       // timing builds (scripts/seq_bench.hip) record the cycle counter of one workgroup here
+#endif
 
 namespace slamk {
 
@@ -73,6 +82,7 @@ __global__ void __launch_bounds__(512) seq_update_kernel(FilterView fv, double* 
             tcs[buf * 16 + tid] = tc;
         }
     };
+    SEQ_STAMP(0);
     if (nchunk > 0) request_rows(0);
     for (int t = wave; t < NPT; t += 8) {                // lower tiles of P
         int I = 0;
@@ -85,12 +95,14 @@ __global__ void __launch_bounds__(512) seq_update_kernel(FilterView fv, double* 
     if (tid < NL) dxs[tid] = 0.0;
     store_rows(0);
     __syncthreads();
+    SEQ_STAMP(1);
 
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
         const double* tb = tab + buf * 128;
         const int* cs = tcs + buf * 16;
         if (c + 1 < nchunk) request_rows(c + 1);
+        if (c == 5) SEQ_STAMP(2);
         // ---- W_c = P H_c^T and e' = e_c - H_c dx ----------------------------------------------------------------------
         for (int idx = tid; idx < NL * 16; idx += 512) {
             const int a = idx >> 4, k = idx & 15;
@@ -114,6 +126,7 @@ __global__ void __launch_bounds__(512) seq_update_kernel(FilterView fv, double* 
             ev[k] = v;
         }
         __syncthreads();
+        if (c == 5) SEQ_STAMP(4);
         // ---- S_c = H_c W_c + R_c in accumulator layout, factor, inverse: one wavefront, registers --------------------
         if (wave == 0) {
             v4d s;
@@ -133,9 +146,11 @@ __global__ void __launch_bounds__(512) seq_update_kernel(FilterView fv, double* 
                 s[r] = v + (q == li ? h[7] : 0.0);
             }
             // S_c is symmetric up to rounding; the routine reads it as such (row li of a pivot column from column li)
+            if (c == 5) SEQ_STAMP(5);
             diag_tile_factor_invert_acc(s, linv, nullptr, 0, lane);
         }
         __syncthreads();
+        if (c == 5) SEQ_STAMP(7);
         // ---- K_c = W_c inv(L_c)^T inv(L_c), by row blocks: K^T = inv(L)^T (inv(L) W^T) ------------------------------
         for (int blk = wave; blk < NT; blk += 8) {
             v4d wt;
@@ -148,6 +163,7 @@ __global__ void __launch_bounds__(512) seq_update_kernel(FilterView fv, double* 
         }
         store_rows(buf ^ 1);
         __syncthreads();
+        if (c == 5) SEQ_STAMP(9);
         // ---- P <- P - K_c W_c^T on the lower tiles; dx <- dx + K_c e' ------------------------------------------------
         for (int t = wave; t < NPT; t += 8) {
             int I = 0;
@@ -174,7 +190,9 @@ __global__ void __launch_bounds__(512) seq_update_kernel(FilterView fv, double* 
             dxs[tid] = v;
         }
         __syncthreads();
+        if (c == 5) SEQ_STAMP(11);
     }
+    SEQ_STAMP(12);
 
     // ---- store: every lower tile with its mirror image; diagonal tiles from their lower half -------------------------
     if (dx && tid < NL) dx[(long long)b * ldn + tid] = dxs[tid];
