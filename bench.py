@@ -487,7 +487,16 @@ def main():
             out["also"] = {"single_filter": single_filter_latency(torch, dev), "large_map": large_map(torch, dev),
                            "ceilings": ceilings(torch, dev),
                            "sweep": [sweep_point(torch, dev, nf_, B_) for nf_, B_ in
-                                     ((8, 4096), (20, 4096), (32, 512), (32, 16384), (60, 1024))]}
+                                     ((8, 4096), (20, 4096), (32, 512), (32, 16384), (36, 1024), (40, 1024), (48, 1024),
+                                      (60, 1024))],
+                           # update_form = 2 (not the default, not what `value` measures): the measurement rows 16 at a
+                           # time against the covariance in LDS; same posterior up to rounding, n <= 160 only
+                           "block_sequential_form": {
+                               "what": "slamk_params.update_form = 2, same step and inputs as the sweep points; the "
+                                       "default form (Cholesky gain of the whole measurement vector + Joseph update) "
+                                       "is what `value` and `roofline` measure",
+                               "points": [sweep_point(torch, dev, nf_, B_, form=2) for nf_, B_ in
+                                          ((8, 4096), (20, 4096), (32, 4096), (36, 1024), (40, 1024), (48, 1024))]}}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
