@@ -426,9 +426,11 @@ def main():
         pred_ms = prof["struct_predict"][0] / K
         pred_bytes = 2.0 * B * nl * nl * 8
         kernels = [
-            {"kernel": "joseph_kernel (A = I - K H, A P, (A P) A^T + K R K^T)", "bound": "mfma", "ms": cov_ms,
+            {"kernel": "joseph_merged_kernel (K R K^T, A = I - K H and dx = K e on one pass over K; A P; (A P) A^T)"
+                       if nl <= 112 else "joseph_kernel (A = I - K H, A P, (A P) A^T + K R K^T)", "bound": "mfma", "ms": cov_ms,
              "achieved": cov_flops / (cov_ms * 1e-3) / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-             "frac": cov_flops / (cov_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS, "traffic": pmc_bytes("joseph_kernel"),
+             "frac": cov_flops / (cov_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
+             "traffic": pmc_bytes("joseph_merged_kernel" if nl <= 112 else "joseph_kernel"),
              "executed_tile_flops_frac": cov_exec_flops / (cov_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS},
             {"kernel": "predict_cov_kernel (P = F P F^T + Q, F in compact row form)", "bound": "hbm", "ms": pred_ms,
              "achieved": pred_bytes / (pred_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
