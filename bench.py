@@ -434,7 +434,7 @@ def main():
              "executed_tile_flops_frac": cov_exec_flops / (cov_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS},
             {"kernel": "predict_cov_kernel (P = F P F^T + Q, F in compact row form)", "bound": "hbm", "ms": pred_ms,
              "achieved": pred_bytes / (pred_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": pred_bytes / (pred_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_bytes("predict_cov_kernel")},
+             "frac": pred_bytes / (pred_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_bytes("predict_cov_band_kernel")},
         ]
         mfma_ms = solver_ms + cov_ms
         dense_flops = 8.0 * n ** 3 + 6.0 * n * n * m + 4.0 * n * m * m + m ** 3 / 3.0 + 2.0 * n * m
