@@ -170,11 +170,13 @@ def ceilings(torch, dev):
     return out
 
 
-def single_filter_latency(torch, dev, nf=20, iters=40):
+def single_filter_latency(torch, dev, nf=20, iters=40, form=0):
     """configs[1]: one filter, 20 features, latency of one predict+update on one GPU (host-driven)."""
     from slam_amd import ekf
     st, steps = build_inputs(torch, dev, 1, nf, iters + 5, 0)
-    fb = ekf.FilterBatch(max_features=nf, batch=1, device=dev.index or 0)
+    prm = ekf.default_params()
+    prm.update_form = form
+    fb = ekf.FilterBatch(max_features=nf, batch=1, device=dev.index or 0, params=prm)
     fb.set_state(0, X=st.init_pos)
     fb.frame(0, first_frame(st), st.steps[0].quat)
     s0 = torch.cuda.Stream(device=dev)
@@ -205,7 +207,7 @@ def single_filter_latency(torch, dev, nf=20, iters=40):
     t_iter = (time.perf_counter() - t1) / iters
     fb.close()
     return {"workload": "single filter, %d features (n=%d), slamk_step_dev in graph mode, host-synchronised every update"
-                        % (nf, 9 + 3 * nf),
+                        % (nf, 9 + 3 * nf), "update_form": form,
             "latency_us_per_update": t * 1e6, "latency_us_iteration_only": t_iter * 1e6}
 
 
@@ -486,7 +488,9 @@ def main():
         del steps
         torch.cuda.empty_cache()
         if world == 1 and not args.no_extra:
-            out["also"] = {"single_filter": single_filter_latency(torch, dev), "large_map": large_map(torch, dev),
+            out["also"] = {"single_filter": single_filter_latency(torch, dev),
+                           "single_filter_block_sequential": single_filter_latency(torch, dev, form=2),
+                           "large_map": large_map(torch, dev),
                            "ceilings": ceilings(torch, dev),
                            "sweep": [sweep_point(torch, dev, nf_, B_) for nf_, B_ in
                                      ((8, 4096), (20, 4096), (32, 512), (32, 16384), (36, 1024), (40, 1024), (48, 1024),

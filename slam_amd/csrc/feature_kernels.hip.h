@@ -212,13 +212,11 @@ __global__ void __launch_bounds__(256) frame_begin_kernel(FilterView fv, int b_o
 // One thread per feature slot; thread (0,0) of each filter also writes the altitude row, and all threads
 // fill the padding rows [m, ml) with e = 0, r = 1, H = 0.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) measure_kernel(FilterView fv, const double* __restrict__ qbw,
-                                                      const double* __restrict__ alt,
-                                                      const double* __restrict__ msrc,
-                                                      const double* __restrict__ mrefl, int ml)
+// Thread i of `stride` threads working on filter b (no barrier inside).
+__device__ __forceinline__ void measure_filter(const FilterView& fv, int b, int i, int stride,
+                                               const double* __restrict__ qbw, const double* __restrict__ alt,
+                                               const double* __restrict__ msrc, const double* __restrict__ mrefl, int ml)
 {
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * 64 + threadIdx.x;
     const int nf = fv.nf[b], m = fv.m[b];
     const long long rb = (long long)b * fv.ldm;
     double* ha = fv.ha + rb * 3;
@@ -240,7 +238,7 @@ __global__ void __launch_bounds__(64) measure_kernel(FilterView fv, const double
         hb[3 * ia] = hb[3 * ia + 1] = hb[3 * ia + 2] = 0.0;
         hcs[ia] = -1;
     }
-    for (int q = m + i; q < ml; q += gridDim.x * 64) {      // padding rows
+    for (int q = m + i; q < ml; q += stride) {              // padding rows
         e[q] = 0.0; rd[q] = 1.0; hcs[q] = -1;
         for (int c = 0; c < 3; ++c) { ha[3 * q + c] = 0.0; hb[3 * q + c] = 0.0; }
     }
@@ -334,6 +332,14 @@ __global__ void __launch_bounds__(64) measure_kernel(FilterView fv, const double
                 hb[3 * (row + 4 + r) + c] = Jp[3 * r] * Mp[c] + Jp[3 * r + 1] * Mp[3 + c] + Jp[3 * r + 2] * Mp[6 + c];
         }
     }
+}
+
+__global__ void __launch_bounds__(64) measure_kernel(FilterView fv, const double* __restrict__ qbw,
+                                                      const double* __restrict__ alt,
+                                                      const double* __restrict__ msrc,
+                                                      const double* __restrict__ mrefl, int ml)
+{
+    measure_filter(fv, blockIdx.y, blockIdx.x * 64 + threadIdx.x, gridDim.x * 64, qbw, alt, msrc, mrefl, ml);
 }
 
 // Dense H (ml x nl) from the compact rows.

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include "gain_solver.hip.h"
+#include "structured_kernels.hip.h"
 
 #ifndef SEQ_STAMP
 #define SEQ_STAMP(i)       // timing builds (scripts/seq_bench.hip) record the cycle counter of one workgroup here
@@ -35,11 +36,12 @@ struct SeqUpdateLds {
     static constexpr int TILES = NT * (NT + 1) / 2 + 2 * NT + 4;
 };
 
-template <int NT>
-__global__ void __launch_bounds__(512) seq_update_kernel(FilterView fv, double* __restrict__ dx, int apply,
-                                                          int* __restrict__ applied)
+// The update of filter b by the whole workgroup.  PRELOADED: the lower tiles of the covariance are already in `lds`
+// (and a barrier has been passed since they were written).
+template <int NT, bool PRELOADED>
+__device__ __forceinline__ void seq_update_filter(const FilterView& fv, int b, double* __restrict__ lds,
+                                                   double* __restrict__ dx, int apply, int* __restrict__ applied)
 {
-    extern __shared__ double lds[];
     constexpr int NL = 16 * NT, NPT = NT * (NT + 1) / 2;
     double* wp = lds + NPT * 256;                        // W_c: NT tiles, rows = states, 16 columns
     double* kp = wp + NT * 256;                          // K_c, same shape
@@ -49,7 +51,6 @@ __global__ void __launch_bounds__(512) seq_update_kernel(FilterView fv, double* 
     double* ev = dxs + NL;                               // [16] e_c - H_c dx
     int* tcs = reinterpret_cast<int*>(ev + 16);          // [2][16] first column of the feature entries (-1: none)
     static_assert(256 + NL + 16 + 16 <= 3 * 256, "LDS layout");
-    const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int ldn = fv.ldn;
@@ -84,13 +85,15 @@ __global__ void __launch_bounds__(512) seq_update_kernel(FilterView fv, double* 
     };
     SEQ_STAMP(0);
     if (nchunk > 0) request_rows(0);
-    for (int t = wave; t < NPT; t += 8) {                // lower tiles of P
-        int I = 0;
-        while ((I + 1) * (I + 2) / 2 <= t) ++I;
-        const int J = t - I * (I + 1) / 2;
+    if constexpr (!PRELOADED) {
+        for (int t = wave; t < NPT; t += 8) {            // lower tiles of P
+            int I = 0;
+            while ((I + 1) * (I + 2) / 2 <= t) ++I;
+            const int J = t - I * (I + 1) / 2;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            lds[t * 256 + tsw(lk + 4 * r, li)] = Pb[(long long)(16 * I + lk + 4 * r) * ldn + 16 * J + li];
+            for (int r = 0; r < 4; ++r)
+                lds[t * 256 + tsw(lk + 4 * r, li)] = Pb[(long long)(16 * I + lk + 4 * r) * ldn + 16 * J + li];
+        }
     }
     if (tid < NL) dxs[tid] = 0.0;
     store_rows(0);
@@ -230,6 +233,158 @@ __global__ void __launch_bounds__(512) seq_update_kernel(FilterView fv, double* 
             }
         }
     }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(512) seq_update_kernel(FilterView fv, double* __restrict__ dx, int apply,
+                                                          int* __restrict__ applied)
+{
+    extern __shared__ double lds[];
+    seq_update_filter<NT, false>(fv, blockIdx.x, lds, dx, apply, applied);
+}
+
+// P <- F P F^T + Q (calcP, src/slam/main.cpp:526-530 with G = I) on the lower tiles of P in LDS.  Row j of F in compact
+// form: fa[j][0..2] on columns 3..5 (the velocity), fg[j][0..2] on columns gs[j] .. + 2; the three rows of a triple share
+// their group, which is the triple itself except for the velocity rows, whose group is the bias triple.  A thread owns
+// 3 x 3 blocks (row triple tj, column triple tl >= tj) of the result, each of which depends on the 6 x 6 entries
+// P[{g_j.., 3..5}][{g_l.., 3..5}]: its own block, and entries of the velocity and bias rows (or, by symmetry, columns).
+// Those six rows are copied aside first, so every block is updated in place.
+// `aux`: free LDS of at least 6 NL + 18 NTR + NL + NL / 2 doubles (NL = 16 NT, NTR = ceil(NL / 3)).
+// Two barriers inside, the second at the end; the image must be complete on entry.
+template <int NT>
+__device__ __forceinline__ void predict_lower_image(const FilterView& fv, int b, double* __restrict__ lds,
+                                                     double* __restrict__ aux)
+{
+    constexpr int NL = 16 * NT, NTR = (NL + 2) / 3;
+    constexpr int TASKS = ((NTR + 1) / 2) * (NTR + 1);               // rows tj and NTR - 1 - tj together: NTR + 1 blocks
+    const int tid = threadIdx.x;
+    auto plow = [&](int r, int c) -> double& {                       // storage of P[r][c] = P[c][r]
+        const int I = r >> 4, J = c >> 4;
+        return I >= J ? lds[tile_index(I, J) * 256 + tsw(r & 15, c & 15)] : lds[tile_index(J, I) * 256 + tsw(c & 15, r & 15)];
+    };
+    double* sv = aux;                                                // old rows 3..5
+    double* sb = sv + 3 * NL;                                        // old rows nb .. nb + 2
+    double* pfa = sb + 3 * NL;                                       // [3 NTR][3], zero past NL
+    double* pfg = pfa + 9 * NTR;
+    double* pq = pfg + 9 * NTR;                                      // [NL]
+    int* pgs = reinterpret_cast<int*>(pq + NL);                      // [NL]
+    const long long cbn = (long long)b * fv.ldn;
+    for (int t = tid; t < 9 * NTR; t += 512) {
+        const bool ok = t < 3 * NL;
+        pfa[t] = ok ? fv.fa[cbn * 3 + t] : 0.0;
+        pfg[t] = ok ? fv.fg[cbn * 3 + t] : 0.0;
+    }
+    for (int t = tid; t < NL; t += 512) { pgs[t] = fv.fgs[cbn + t]; pq[t] = fv.qdiag[cbn + t]; }
+    const int nb = fv.fgs[cbn + 3];                                  // first bias row
+    for (int t = tid; t < 3 * NL; t += 512) {
+        const int r = t / NL, c = t - r * NL;
+        sv[t] = plow(3 + r, c);
+        sb[t] = plow(min(nb + r, NL - 1), c);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int k = tid; k < TASKS; k += 512) {
+        const int p = k / (NTR + 1), idx = k - p * (NTR + 1);
+        int tj = p, tl = p + idx;
+        if (idx >= NTR - p) {
+            if (2 * p == NTR - 1) continue;                          // (odd NTR: the middle row only once)
+            tj = NTR - 1 - p; tl = tj + (idx - (NTR - p));
+        }
+        const int j0 = 3 * tj, l0 = 3 * tl;
+        const int gj = pgs[min(j0, NL - 1)], gl = pgs[min(l0, NL - 1)];
+        // column coefficients: fgl[3 c + k] on column gl + k, fal[3 c + k] on column 3 + k
+        const double* fgl = pfg + 3 * l0;
+        const double* fal = pfa + 3 * l0;
+        double acc[3][3];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                                // h = 0: the rows of the group, h = 1: rows 3..5
+#pragma unroll
+            for (int aa = 0; aa < 3; ++aa) {
+                double pg[3], pv[3];                                 // old P[a][gl + k], old P[a][3 + k]
+                if (h == 1) {
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk) { pg[kk] = sv[aa * NL + min(gl + kk, NL - 1)]; pv[kk] = sv[aa * NL + 3 + kk]; }
+                } else {
+                    const int a = min(gj + aa, NL - 1);
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk) {
+                        const int bq = min(gl + kk, NL - 1);
+                        pg[kk] = tj == 1 ? sb[aa * NL + bq] : (tl == 1 ? sb[kk * NL + a] : plow(a, bq));
+                        pv[kk] = sv[kk * NL + a];                    // P[a][3 + k] = P[3 + k][a]
+                    }
+                }
+                double t[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    double sacc = pg[0] * fgl[3 * c];
+                    sacc = fma(pg[1], fgl[3 * c + 1], sacc); sacc = fma(pg[2], fgl[3 * c + 2], sacc);
+                    sacc = fma(pv[0], fal[3 * c], sacc); sacc = fma(pv[1], fal[3 * c + 1], sacc); sacc = fma(pv[2], fal[3 * c + 2], sacc);
+                    t[c] = sacc;
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const double f = h == 0 ? pfg[3 * (j0 + r) + aa] : pfa[3 * (j0 + r) + aa];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) acc[r][c] = (h == 0 && aa == 0) ? f * t[c] : fma(f, t[c], acc[r][c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int j = j0 + r, l = l0 + c;
+                if (j < NL && l < NL && (tj != tl || l >= j)) {
+                    const double v = acc[r][c] + (j == l ? pq[j] : 0.0);
+                    plow(l, j) = v;                                  // (l >= j within a block of the upper half)
+                    if ((j >> 4) == (l >> 4)) lds[tile_index(j >> 4, j >> 4) * 256 + tsw(j & 15, l & 15)] = v;   // diagonal tiles are kept whole
+                }
+            }
+    }
+    __syncthreads();
+}
+
+// One whole iteration with an image (src/slam/main.cpp:167-233 without the association) of a small filter in ONE
+// launch, for callers that pay for launches, not work (a single filter, a handful of them): frame begin, compact rows
+// of F at the state before the motion, mu += dynamics(mu) dt, the covariance propagated on its lower tiles in LDS,
+// measurement rows at the new state, the block-sequential update above, gate and mean update.  The covariance is
+// read once and written once; F, H, e and R pass through memory for the other kernels' sake (introspection).
+// Same arithmetic as the separate kernels up to the summation order of the propagation.
+template <int NT>
+__global__ void __launch_bounds__(512) seq_step_kernel(FilterView fv, const double* __restrict__ qbw,
+                                                        const double* __restrict__ w, const double* __restrict__ acc,
+                                                        const double* __restrict__ dtv, const double* __restrict__ alt,
+                                                        const double* __restrict__ msrc, const double* __restrict__ mrefl,
+                                                        int ml, int frame, double* __restrict__ dx, int apply,
+                                                        int* __restrict__ applied)
+{
+    extern __shared__ double lds[];
+    constexpr int NL = 16 * NT, NPT = NT * (NT + 1) / 2;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int ldn = fv.ldn;
+    const double* Pb = fv.P + (long long)b * ldn * ldn;
+    for (int t = wave; t < NPT; t += 8) {                // the lower tiles of P: in flight during the small steps below
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= t) ++I;
+        const int J = t - I * (I + 1) / 2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            lds[t * 256 + tsw(lk + 4 * r, li)] = Pb[(long long)(16 * I + lk + 4 * r) * ldn + 16 * J + li];
+    }
+    if (frame) {
+        frame_begin_filter(fv, b);
+        __syncthreads();                    // the clamped depths are read by the rows of F and by the dynamics
+    }
+    const double dt = dtv[b];
+    for (int j = tid; j < NL; j += 512) motion_row(fv, b, j, qbw, w, dt);
+    __syncthreads();                        // F is taken at the state before the dynamics move it
+    dynamics_filter(fv, b, qbw, w, acc, dtv);
+    __syncthreads();
+    measure_filter(fv, b, tid, 512, qbw, alt, msrc, mrefl, ml);
+    predict_lower_image<NT>(fv, b, lds, lds + NPT * 256);             // (the panels of the update are not in use yet)
+    seq_update_filter<NT, true>(fv, b, lds, dx, apply, applied);
 }
 
 }  // namespace slamk

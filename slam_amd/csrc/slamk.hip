@@ -697,6 +697,63 @@ int launch_seq_update(slamk_handle* h, const Range& rg, int* applied, hipStream_
     return 0;
 }
 
+// A whole iteration with an image in one launch (seq_step_kernel), update_form 2: for small batches, where a step costs
+// launches rather than work, and for filters of 81 states and more at any batch size, where saving the propagation's
+// pass over the covariance outweighs a workgroup of 512 threads per filter for the small steps (measured at 4096
+// filters: 32 features 1.57 -> 1.45 ms per step, 20 features equal, 8 features 0.31 -> 0.40 ms).
+// SLAMK_SEQ_STEP_MAXB overrides the largest batch of smaller filters that takes it (default 256).
+bool use_seq_step(const slamk_handle* h)
+{
+    static const int maxb = [] { const char* e = getenv("SLAMK_SEQ_STEP_MAXB"); return e ? atoi(e) : 256; }();
+    const int nl = max_nl(h);
+    return use_seq_update(h, nl) && !keep_dense(h, nl) && (h->B <= maxb || nl >= 96);
+}
+
+template <int NT>
+int launch_seq_step(slamk_handle* h, const Range& rg, const double* qbw, const double* w, const double* acc, const double* dt,
+                    const double* alt, const double* src, const double* refl, int ml, bool frame, int* applied, hipStream_t st)
+{
+    const size_t lds = (size_t)SeqUpdateLds<NT>::TILES * 256 * sizeof(double);
+    { int rc_ = ensure_dynamic_lds(h, reinterpret_cast<const void*>(seq_step_kernel<NT>), lds); if (rc_) return rc_; }
+    hipLaunchKernelGGL(seq_step_kernel<NT>, dim3(rg.B), dim3(512), lds, st, rg.fv, qbw, w, acc, dt, alt, src, refl, ml,
+                       frame ? 1 : 0, fuse_apply(rg.B) ? (double*)nullptr : rg.dx, fuse_apply(rg.B) ? 1 : 0, applied);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int run_seq_step(slamk_handle* h, const Range& rg, const double* qbw, const double* w, const double* acc, const double* dt,
+                 const double* alt, const double* src, const double* refl, bool frame, int* applied, hipStream_t st)
+{
+    const int nl = max_nl(h), ml = max_ml(h);
+    h->last_nl = nl; h->last_ml = ml;
+    if (!src) src = rg.fv.msrc;
+    if (!refl) refl = rg.fv.mrefl;
+    int rc = 0;
+    {
+        ProfScope ps(h, PC_GEMM_COV, st);
+        switch (nl / 16) {
+            case 1: rc = launch_seq_step<1>(h, rg, qbw, w, acc, dt, alt, src, refl, ml, frame, applied, st); break;
+            case 2: rc = launch_seq_step<2>(h, rg, qbw, w, acc, dt, alt, src, refl, ml, frame, applied, st); break;
+            case 3: rc = launch_seq_step<3>(h, rg, qbw, w, acc, dt, alt, src, refl, ml, frame, applied, st); break;
+            case 4: rc = launch_seq_step<4>(h, rg, qbw, w, acc, dt, alt, src, refl, ml, frame, applied, st); break;
+            case 5: rc = launch_seq_step<5>(h, rg, qbw, w, acc, dt, alt, src, refl, ml, frame, applied, st); break;
+            case 6: rc = launch_seq_step<6>(h, rg, qbw, w, acc, dt, alt, src, refl, ml, frame, applied, st); break;
+            case 7: rc = launch_seq_step<7>(h, rg, qbw, w, acc, dt, alt, src, refl, ml, frame, applied, st); break;
+            case 8: rc = launch_seq_step<8>(h, rg, qbw, w, acc, dt, alt, src, refl, ml, frame, applied, st); break;
+            case 9: rc = launch_seq_step<9>(h, rg, qbw, w, acc, dt, alt, src, refl, ml, frame, applied, st); break;
+            case 10: rc = launch_seq_step<10>(h, rg, qbw, w, acc, dt, alt, src, refl, ml, frame, applied, st); break;
+            default: rc = fail(h, SLAMK_EINVAL, "one-launch step: n = %d out of range", nl);
+        }
+    }
+    if (rc) return rc;
+    if (!fuse_apply(rg.B)) {
+        ProfScope ps_tail(h, PC_FEATURE, st);
+        hipLaunchKernelGGL(gain_apply_kernel, dim3(rg.B), dim3(256), 0, st, rg.fv, rg.dx, applied);
+    }
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 int run_seq_update(slamk_handle* h, const Range& rg, int nl, int* applied, hipStream_t st)
 {
     ProfScope ps(h, PC_GEMM_COV, st);
@@ -819,7 +876,7 @@ int run_update(slamk_handle* h, const Range& rg, const double* qbw, const double
 }
 
 // Launch sequence of one whole iteration (frame begin, predict, update) for all filters, in `groups` ranges.
-// Leaves the propagated covariance in the T buffer: the caller swaps P and T.
+// Leaves the updated covariance in the T buffer (the caller swaps P and T) unless use_seq_step(h): then in P itself.
 int step_launch(slamk_handle* h, const double* qbw_dev, const double* w_dev, const double* acc_dev, const double* dt_dev,
                 const double* alt_dev, const double* src_dev, const double* refl_dev, int32_t* applied_dev,
                 hipStream_t st, int groups, bool frame_begin)
@@ -835,6 +892,7 @@ int step_launch(slamk_handle* h, const double* qbw_dev, const double* w_dev, con
     }
     if (G > 1 && !h->fork) HIPCHK(h, hipEventCreateWithFlags(&h->fork, hipEventDisableTiming));
     const size_t F = h->F;
+    const bool one_launch = use_seq_step(h);
     if (G > 1) HIPCHK(h, hipEventRecord(h->fork, st));
     int rc = 0;
     for (int g = 0; g < G; ++g) {
@@ -844,12 +902,19 @@ int step_launch(slamk_handle* h, const double* qbw_dev, const double* w_dev, con
         if (G > 1) he = hipStreamWaitEvent(gs, h->fork, 0);
         if (!rc && he == hipSuccess) {
             const Range rp = make_range(h, b0, b1 - b0);
+            if (one_launch)         // the covariance stays in its buffer: the caller does not exchange P and T
+                rc = run_seq_step(h, rp, qbw_dev + 4 * (size_t)b0, w_dev + 3 * (size_t)b0, acc_dev + 3 * (size_t)b0, dt_dev + b0,
+                                  (alt_dev ? alt_dev : h->alt_d) + b0, src_dev ? src_dev + 2 * F * b0 : nullptr,
+                                  refl_dev ? refl_dev + 2 * F * b0 : nullptr, frame_begin,
+                                  applied_dev ? applied_dev + b0 : nullptr, gs);
+            else {
             rc = run_predict(h, rp, qbw_dev + 4 * (size_t)b0, w_dev + 3 * (size_t)b0, acc_dev + 3 * (size_t)b0, dt_dev + b0,
                              gs, frame_begin);
             if (!rc)
                 rc = run_update(h, after_predict(rp), qbw_dev + 4 * (size_t)b0, (alt_dev ? alt_dev : h->alt_d) + b0,
                                 src_dev ? src_dev + 2 * F * b0 : nullptr, refl_dev ? refl_dev + 2 * F * b0 : nullptr,
                                 applied_dev ? applied_dev + b0 : nullptr, gs);
+            }
         }
         // every forked stream is joined back into `st`, also after a failure: the caller's stream never ends up
         // ahead of work that this call queued
@@ -1403,14 +1468,14 @@ int slamk_step_dev(slamk_handle* h, const double* qbw_dev, const double* w_dev, 
             hit = &h->graphs.back();
         }
         HIPCHK(h, hipGraphLaunch(hit->exec, st));
-        std::swap(h->fv.P, h->T);
+        if (!use_seq_step(h)) std::swap(h->fv.P, h->T);
         h->clear_begun();
         return SLAMK_OK;
     }
     int rc = step_launch(h, qbw_dev, w_dev, acc_dev, dt_dev, alt_dev, src_dev, refl_dev, applied_dev, st, h->groups,
                          frame_begin);
     if (rc) return rc;                 // P still names the buffer that holds the last complete covariance
-    std::swap(h->fv.P, h->T);
+    if (!use_seq_step(h)) std::swap(h->fv.P, h->T);
     h->clear_begun();
     return SLAMK_OK;
 }
