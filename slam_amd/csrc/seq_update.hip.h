@@ -6,25 +6,25 @@
 // gives the same posterior covariance and the same total correction dx = K e as one gain for the whole measurement
 // vector (calcK / updateP / K * eeMat, src/slam/main.cpp:221-228) in exact arithmetic; the gate and the mean update
 // (:229-232) use the total dx as there.  It is NOT the reference's sequence of operations (one m x m system), so it
-// is an option beside the default, held to the same tolerance.  Work per update: ~ (NT (NT + 1) / 2 + 2 NT) tile
-// products per chunk instead of an m x m factorisation, two n x m triangular solves and three n x n products;
-// neither S nor K ever exists in memory, and P is read and written once.
+// is an option beside the default, held to the same tolerance.
+// With Y_c = W_c L_c^-T:  K_c W_c^T = Y_c Y_c^T  and  K_c e' = Y_c (L_c^-1 e'), so the gain is never formed: per chunk
+// one tile product per row block for Y_c and NT (NT + 1) / 2 for the symmetric downdate of P, instead of an m x m
+// factorisation, two n x m triangular solves and three n x n products.  Neither S nor K exists in memory; P is read
+// and written once.
 //
 // LDS: the lower tiles of P (NT (NT + 1) / 2, tile (I, J), I >= J, at tile_index(I, J); symmetric reads go through the
-// transposed tile), the panels W_c and K_c (NT tiles each), inv(L_c), the chunk's compact rows of H (two buffers).
-// n <= 160 (NT <= 10): 79 tiles.  Per chunk four barriers: W_c and e' -> S_c, factor, inverse (one wavefront, in
-// registers) -> K_c -> P and dx.  Cycle stamps at 32 features (scripts/seq_bench.hip): 14k to load P, then per chunk
-// W_c 2.6k, S_c 0.9k + factorisation and inverse 4.3k (one wavefront, the others wait), K_c 1.6k, P and dx 4.9k;
-// 180k per filter.  Measured no faster: K_c kept in registers with the tiles of a row block done by the wavefront that
-// owns it (one panel and one barrier less, 76 KB of LDS so that two workgroups share a compute unit, but 1 .. NT tiles
-// per wavefront and 128 registers per lane, which the factorisation in registers does not fit), and the lower tiles
-// dealt evenly, two at a time.
+// transposed tile), the panel W_c / Y_c (NT tiles), inv(L_c), the chunk's compact rows of H (two buffers): 39 tiles at
+// n <= 112, 69 at n = 160.  Per chunk four barriers: W_c and e' -> S_c, factor, inverse (one wavefront, in registers)
+// -> Y_c and z -> P and dx.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include "gain_solver.hip.h"
 #include "structured_kernels.hip.h"
 
+#ifndef SEQ_WAVES_PER_EU
+#define SEQ_WAVES_PER_EU 2
+#endif
 #ifndef SEQ_STAMP
 #define SEQ_STAMP(i)       // timing builds (scripts/seq_bench.hip) record the cycle counter of one workgroup here
 #endif
@@ -33,7 +33,7 @@ namespace slamk {
 
 template <int NT>
 struct SeqUpdateLds {
-    static constexpr int TILES = NT * (NT + 1) / 2 + 2 * NT + 4;
+    static constexpr int TILES = NT * (NT + 1) / 2 + NT + 4;
 };
 
 // The update of filter b by the whole workgroup.  PRELOADED: the lower tiles of the covariance are already in `lds`
@@ -43,14 +43,14 @@ __device__ __forceinline__ void seq_update_filter(const FilterView& fv, int b, d
                                                    double* __restrict__ dx, int apply, int* __restrict__ applied)
 {
     constexpr int NL = 16 * NT, NPT = NT * (NT + 1) / 2;
-    double* wp = lds + NPT * 256;                        // W_c: NT tiles, rows = states, 16 columns
-    double* kp = wp + NT * 256;                          // K_c, same shape
-    double* linv = kp + NT * 256;                        // inv(L_c)
+    double* wp = lds + NPT * 256;                        // W_c, then Y_c: NT tiles, rows = states, 16 columns
+    double* linv = wp + NT * 256;                        // inv(L_c)
     double* tab = linv + 256;                            // [2][16][8]: ha[3], hb[3], e, r of the chunk's rows
     double* dxs = tab + 256;                             // [NL]
-    double* ev = dxs + NL;                               // [16] e_c - H_c dx
-    int* tcs = reinterpret_cast<int*>(ev + 16);          // [2][16] first column of the feature entries (-1: none)
-    static_assert(256 + NL + 16 + 16 <= 3 * 256, "LDS layout");
+    double* ev = dxs + NL;                               // [16] e' = e_c - H_c dx
+    double* zv = ev + 16;                                // [16] inv(L_c) e'
+    int* tcs = reinterpret_cast<int*>(zv + 16);          // [2][16] first column of the feature entries (-1: none)
+    static_assert(256 + NL + 16 + 16 + 16 <= 3 * 256, "LDS layout");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int ldn = fv.ldn;
@@ -154,41 +154,80 @@ __device__ __forceinline__ void seq_update_filter(const FilterView& fv, int b, d
         }
         __syncthreads();
         if (c == 5) SEQ_STAMP(7);
-        // ---- K_c = W_c inv(L_c)^T inv(L_c), by row blocks: K^T = inv(L)^T (inv(L) W^T) ------------------------------
+        // ---- Y_c = W_c inv(L_c)^T by row blocks, in place of W_c (Y^T = inv(L) W^T), and z = inv(L_c) e' ----------------
+        // K_c W_c^T = Y_c Y_c^T and K_c e' = Y_c z: the gain itself is never formed.
         for (int blk = wave; blk < NT; blk += 8) {
             v4d wt;
 #pragma unroll
             for (int r = 0; r < 4; ++r) wt[r] = wp[blk * 256 + tsw(li, lk + 4 * r)];
             const v4d yt = tile_mma_regB<false, false>(linv, wt, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
-            const v4d kt = tile_mma_regB<true, false>(linv, yt, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) kp[blk * 256 + tsw(li, lk + 4 * r)] = kt[r];
+            for (int r = 0; r < 4; ++r) wp[blk * 256 + tsw(li, lk + 4 * r)] = yt[r];
+        }
+        if (tid >= 448 && tid < 464) {                   // (wavefront 7 owns at most one row block)
+            const int i = tid - 448;
+            double v = 0.0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                double l4[4];
+                tile_ld4(linv, i, 4 * g, l4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v = fma(l4[k], ev[4 * g + k], v);
+            }
+            zv[i] = v;
         }
         store_rows(buf ^ 1);
         __syncthreads();
         if (c == 5) SEQ_STAMP(9);
-        // ---- P <- P - K_c W_c^T on the lower tiles; dx <- dx + K_c e' ------------------------------------------------
-        for (int t = wave; t < NPT; t += 8) {
-            int I = 0;
-            while ((I + 1) * (I + 2) / 2 <= t) ++I;
-            const int J = t - I * (I + 1) / 2;
-            double* pt = lds + t * 256;
-            v4d acc;
+        // ---- P <- P - Y_c Y_c^T on the lower tiles; dx <- dx + Y_c z --------------------------------------------------
+        // (up to four tiles of a wavefront at a time: independent chains of products instead of one)
+        constexpr int PER_WAVE = (NPT + 7) / 8, PASSES = (PER_WAVE + 3) / 4, SLOTS = (PER_WAVE + PASSES - 1) / PASSES;
+        for (int t0 = __builtin_amdgcn_readfirstlane(wave); t0 < NPT; t0 += 8 * SLOTS) {   // (scalar: the tile indices below too)
+            v4d acc[SLOTS];
+            double2 ya[SLOTS][2], yb[SLOTS][2];
+            const int o0 = li * 16 + ((4 * lk) ^ (li & 14)), o1 = li * 16 + ((4 * lk + 2) ^ (li & 14));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = pt[tsw(lk + 4 * r, li)];
-            acc = tile_mma_ldsBt<true>(kp + I * 256, wp + J * 256, acc, li, lk);
+            for (int u = 0; u < SLOTS; ++u) {
+                const int t = min(t0 + 8 * u, NPT - 1);  // (a slot past the end repeats the last tile and is not stored)
+                int I = 0;
+                while ((I + 1) * (I + 2) / 2 <= t) ++I;
+                const int J = t - I * (I + 1) / 2;
+                const double* pt = lds + t * 256;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pt[tsw(lk + 4 * r, li)] = acc[r];
+                for (int r = 0; r < 4; ++r) acc[u][r] = pt[tsw(lk + 4 * r, li)];
+                ya[u][0] = *reinterpret_cast<const double2*>(wp + I * 256 + o0);
+                ya[u][1] = *reinterpret_cast<const double2*>(wp + I * 256 + o1);
+                yb[u][0] = *reinterpret_cast<const double2*>(wp + J * 256 + o0);
+                yb[u][1] = *reinterpret_cast<const double2*>(wp + J * 256 + o1);
+            }
+#pragma unroll
+            for (int u = 0; u < SLOTS; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ya[u][0].x, yb[u][0].x, acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < SLOTS; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ya[u][0].y, yb[u][0].y, acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < SLOTS; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ya[u][1].x, yb[u][1].x, acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < SLOTS; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ya[u][1].y, yb[u][1].y, acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < SLOTS; ++u) {
+                const int t = t0 + 8 * u;
+                if (t < NPT) {
+                    double* pt = lds + t * 256;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pt[tsw(lk + 4 * r, li)] = acc[u][r];
+                }
+            }
         }
+        if (c == 5) SEQ_STAMP(10);
         if (tid < NL) {
-            const double* kr = kp + (tid >> 4) * 256;
+            const double* yr = wp + (tid >> 4) * 256;
             double v = dxs[tid];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                double k4[4];
-                tile_ld4(kr, tid & 15, 4 * g, k4);
+                double y4[4];
+                tile_ld4(yr, tid & 15, 4 * g, y4);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v = fma(k4[k], ev[4 * g + k], v);
+                for (int k = 0; k < 4; ++k) v = fma(y4[k], zv[4 * g + k], v);
             }
             dxs[tid] = v;
         }
@@ -236,7 +275,7 @@ __device__ __forceinline__ void seq_update_filter(const FilterView& fv, int b, d
 }
 
 template <int NT>
-__global__ void __launch_bounds__(512) seq_update_kernel(FilterView fv, double* __restrict__ dx, int apply,
+__global__ void __launch_bounds__(512, SEQ_WAVES_PER_EU) seq_update_kernel(FilterView fv, double* __restrict__ dx, int apply,
                                                           int* __restrict__ applied)
 {
     extern __shared__ double lds[];

@@ -2039,6 +2039,8 @@ int slamk_debug_get(slamk_handle* h, int b, double* H, double* L, double* K, dou
 {
     CHECK_B(h, b);
     if ((H || L) && !h->debug) return fail(h, SLAMK_EINVAL, "debug_get: H and L are only kept after slamk_set_debug(h, 1)");
+    if ((K || L) && h->prm.update_form == 2)
+        return fail(h, SLAMK_EINVAL, "debug_get: the block-sequential update (update_form 2) forms neither K nor L");
     ENTER_HOST(h);
     const int n = 9 + 3 * h->hf[b].nf, m = h->hf[b].m();
     const size_t ldn = h->ldn, ldm = h->ldm;
