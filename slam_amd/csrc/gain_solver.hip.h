@@ -395,7 +395,9 @@ template <int MT>
 struct SolverLds {
     static constexpr int M = 16 * MT;
     static constexpr int COEF_TILES = (15 * M / 2 + 255) / 256;          // ha, hb [M][3], r [M], cs [M] (int)
-    static constexpr int EXTRA_TILES = (COEF_TILES + 8 > 9) ? COEF_TILES + 8 : 9;
+    // two panels of W (one barrier per panel instead of two) where 160 KB allow it
+    static constexpr bool TWO_PANELS = MT * (MT + 1) / 2 + COEF_TILES + 16 <= 80;
+    static constexpr int EXTRA_TILES = COEF_TILES + (TWO_PANELS ? 16 : 8);
     static constexpr int TILES = MT * (MT + 1) / 2 + EXTRA_TILES;
 };
 
@@ -437,7 +439,8 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
     double* chb = cha + 3 * M;                           // [M][3]
     double* crd = chb + 3 * M;                           // [M]
     int* ccs = reinterpret_cast<int*>(crd + M);          // [M]
-    double* pan = scratch + SolverLds<MT>::COEF_TILES * 256;   // NT tiles: rows of W, 16 columns
+    double* pan0 = scratch + SolverLds<MT>::COEF_TILES * 256;  // NT tiles: rows of W, 16 columns (x 2 where LDS allows)
+    constexpr bool TWO_PANELS = SolverLds<MT>::TWO_PANELS;
     // The first loads of P (columns 0..2 of every row, and the first panel's feature columns, whose start comes
     // straight from global memory) are requested before the compact rows of H are staged: one global round trip
     // instead of three in a row at the start of the workgroup.
@@ -476,6 +479,7 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
         };
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
+            double* pan = pan0 + ((TWO_PANELS && (j & 1)) ? 8 * 256 : 0);
             {
                 const int q = 16 * j + ec;
 #pragma unroll
@@ -530,7 +534,9 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
                     for (int r = 0; r < 4; ++r) Kpark[(long long)li * ldm + 16 * j + lk + 4 * r] = pan[blk * 256 + tsw(li, lk + 4 * r)];
                 }
             }
-            __syncthreads();
+            // (with two panels the next one is written while stragglers still read this one; the barrier after the
+            // next panel's stores comes before anything overwrites it)
+            if (!TWO_PANELS || j + 1 == MT) __syncthreads();
         }
     };
 
