@@ -71,13 +71,15 @@ __device__ __forceinline__ v4d tile_mma_ldsBt(const double* __restrict__ ta, con
     return c;
 }
 
-// 1/sqrt(a) to double precision: hardware estimate (v_rsq_f64) + two Newton steps.
+// 1/sqrt(a) to double precision: hardware estimate (v_rsq_f64) + one Halley-type step.
 __device__ __forceinline__ double rsqrt_nr(double a)
 {
+    // one third-order step: with r = 1 - a y^2 the exact factor is (1 - r)^-1/2 = 1 + r / 2 + 3 r^2 / 8 + O(r^3); the
+    // estimate is good to 5e-8, so the remainder is far below rounding (measured 2.3e-16 over 40 binades), and the
+    // chain is five dependent operations instead of the eight of two Newton steps.
     double y = __builtin_amdgcn_rsq(a);
-    y = y * (1.5 - 0.5 * a * y * y);
-    y = y * (1.5 - 0.5 * a * y * y);
-    return y;
+    const double r = fma(-(a * y), y, 1.0);
+    return fma(y, r * fma(r, 0.375, 0.5), y);
 }
 
 // Lower triangle of a 4 x 4 block packed by rows: (i, j) at i (i + 1) / 2 + j.
