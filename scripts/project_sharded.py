@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nf", type=int, default=2000)
+    ap.add_argument("--worlds", type=int, nargs="+", default=[1, 2, 4, 8])
     args = ap.parse_args()
     import torch
     from slam_amd import ekf, synth, _lib
@@ -35,7 +36,7 @@ def main():
     s0 = st.steps[0]
     first = [(int(s0.ids[i]), s0.src[i, 0], s0.src[i, 1], s0.refl[i, 0], s0.refl[i, 1]) for i in range(nf)]
     AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
-    for g in (1, 2, 4, 8):
+    for g in args.worlds:
         fb = ekf.FilterBatch(max_features=nf, batch=1, device=0)
         fb.set_state(0, X=st.init_pos)
         fb.frame(0, first, s0.quat)

@@ -99,6 +99,12 @@ def lib():
             raise RuntimeError(
                 "libslamk.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback)" % LIB_PATH)
+        # torch ships its own copy of the HIP runtime: when a process uses both, torch's must be the one that is loaded
+        # first (loaded after this library's, torch reports no GPU).  A process without torch skips this.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

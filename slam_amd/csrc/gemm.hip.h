@@ -19,6 +19,8 @@
 // tile edges are handled by zero-filling loads and guarding stores at that granularity.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdlib>
 
 namespace slamk {
 
@@ -238,6 +240,63 @@ inline hipError_t launch_gemm(const GemmArgs& g, int batch, hipStream_t stream)
         dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, batch);
         hipLaunchKernelGGL((gemm_f64_kernel<64, 64, TB, EPI, LOWER, TRI>), grid, dim3(256), 0, stream, g);
     }
+    return hipGetLastError();
+}
+
+// C = beta C + alpha sum_i P_i over `parts` partial products of M x N doubles (ld N), summed in ascending order.
+// grid (ceil(N / 256), M), 256 threads.
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(double* __restrict__ C, int ldc, const double* __restrict__ P,
+                                                             int M, int N, int parts, double alpha, double beta)
+{
+    const int col = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+    if (col >= N) return;
+    const long long o = (long long)row * N + col, sp = (long long)M * N;
+    double acc = P[o];
+    for (int i = 1; i < parts; ++i) acc += P[o + i * sp];
+    double* c = C + (long long)row * ldc + col;
+    double v = alpha * acc;
+    if (beta != 0.0) v += beta * (*c);
+    *c = v;
+}
+
+// How many slices of the k range fill the GPU for an M x N x K product whose tile grid alone is much smaller than the
+// 256 CUs (a row block of a sharded matrix times a long k range): 1 when the grid is large enough or k is short.
+// SLAMK_SPLITK_MIN_SLICE: shortest slice worth a launch of its own (default 512; tests lower it to reach this path
+// with small matrices).
+inline int splitk_parts(int M, int N, int K, size_t ws_elems)
+{
+    const char* e = getenv("SLAMK_SPLITK_MIN_SLICE");
+    const int min_slice = e ? std::max(16, atoi(e)) : 512;
+    const bool big = (M >= 512 && N >= 512);
+    const int t = big ? 128 : 64;
+    const long long tiles = (long long)((M + t - 1) / t) * ((N + t - 1) / t);
+    if (tiles >= 200 || K < 4 * min_slice) return 1;
+    int parts = 8;
+    while (parts > 1 && (tiles * parts > 1024 || K / parts < min_slice || K % (16 * parts) != 0 ||
+                         (size_t)parts * M * N > ws_elems))
+        parts /= 2;
+    return parts;
+}
+
+// launch_gemm (one matrix, no epilogue, no triangular trimming) with the k range cut into slices that run as one
+// batched launch into partial products in `ws`, then summed into C in a fixed order (deterministic).
+template <bool TB>
+inline hipError_t launch_gemm_splitk(const GemmArgs& g, double* ws, size_t ws_elems, hipStream_t stream)
+{
+    const int parts = ws ? splitk_parts(g.M, g.N, g.K, ws_elems) : 1;
+    if (parts < 2) return launch_gemm<TB, EPI_NONE, false, TRI_NONE>(g, 1, stream);
+    GemmArgs p = g;
+    p.K = g.K / parts;
+    p.C = ws; p.ldc = g.N;
+    p.sA2 = p.K;
+    p.sB2 = TB ? (long long)p.K : (long long)p.K * g.ldb;
+    p.sC2 = (long long)g.M * g.N;
+    p.nb2 = parts;
+    p.alpha = 1.0; p.beta = 0.0;
+    hipError_t e = launch_gemm<TB, EPI_NONE, false, TRI_NONE>(p, parts, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((g.N + 255) / 256, g.M), dim3(256), 0, stream, g.C, g.ldc, ws, g.M, g.N,
+                       parts, g.alpha, g.beta);
     return hipGetLastError();
 }
 

@@ -499,56 +499,48 @@ int launch_chol_inv_block(slamk_handle* h, double* Sp, double* Lp, double* Lip, 
     }
 }
 
-// S (lower) -> L (Cholesky factor) and Li = the inverses of L's diagonal blocks of INV_BS rows (all of inv(L) when
-// ml <= INV_BS); S is used as scratch afterwards.
-int cholesky_inverse(slamk_handle* h, double* Sp, double* Lp, double* Lip, int ldm, long long sM, int B, int ml,
-                     int* status, hipStream_t st)
+// Columns [J0, J1) of the blocked right-looking Cholesky of S (lower) into L, diagonal-block inverses into Li: the
+// trailing update after every diagonal block of NB rows only reaches the panel's own columns (rank NB).  On entry
+// these columns of S carry the updates of all columns left of J0.
+int chol_outer_panel(slamk_handle* h, double* Sp, double* Lp, double* Lip, int ldm, long long sM, int B, int ml, int J0,
+                     int J1, int* status, hipStream_t st)
 {
-    const int NB = CHOL_NB, OB = chol_outer_block();
-    // Blocked right-looking Cholesky of S (lower) into L, diagonal-block inverses into Li, on two levels: inside
-    // an outer panel of OB columns the trailing update after every diagonal block only reaches the panel's own
-    // columns (rank NB); the columns right of the panel take one rank-OB update when the panel is complete, which
-    // reads and writes the large trailing matrix OB / NB times less often.
-    for (int J0 = 0; J0 < ml; J0 += OB) {
-        const int J1 = std::min(ml, J0 + OB);
-        for (int j0 = J0; j0 < J1; j0 += NB) {
-            const int nb = std::min(NB, ml - j0);
-            {
-                ProfScope ps(h, PC_POTF2, st);
-                int rc = launch_chol_inv_block(h, Sp, Lp, Lip, ldm, sM, B, j0, nb, status, st);
-                if (rc) return rc;
-            }
-            const int rem = ml - j0 - nb;
-            if (rem <= 0) break;
-            ProfScope ps(h, PC_GEMM_CHOL, st);
-            const long long o21 = (long long)(j0 + nb) * ldm + j0, o11 = (long long)j0 * ldm + j0;
-            const long long o22 = (long long)(j0 + nb) * ldm + (j0 + nb);
-            // L21 = S21 inv(L11)^T
-            HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_B_KLE_N>(
-                          gargs(Sp + o21, ldm, sM, Lip + o11, ldm, sM, Lp + o21, ldm, sM, rem, nb, nb), B, st)));
-            // S22 -= L21 L21^T, lower tiles, columns of this outer panel only
-            const int nin = J1 - (j0 + nb);
-            if (nin > 0)
-                HIPCHK(h, (launch_gemm<true, EPI_NONE, true, TRI_NONE>(
-                              gargs(Lp + o21, ldm, sM, Lp + o21, ldm, sM, Sp + o22, ldm, sM, rem, nin, nb, -1.0, 1.0),
-                              B, st)));
+    const int NB = CHOL_NB;
+    for (int j0 = J0; j0 < J1; j0 += NB) {
+        const int nb = std::min(NB, ml - j0);
+        {
+            ProfScope ps(h, PC_POTF2, st);
+            int rc = launch_chol_inv_block(h, Sp, Lp, Lip, ldm, sM, B, j0, nb, status, st);
+            if (rc) return rc;
         }
-        const int remo = ml - J1;
-        if (remo > 0) {          // the rest of the trailing matrix: one update of rank J1 - J0
-            ProfScope ps(h, PC_GEMM_CHOL, st);
-            const long long oL = (long long)J1 * ldm + J0, oS = (long long)J1 * ldm + J1;
+        const int rem = ml - j0 - nb;
+        if (rem <= 0) break;
+        ProfScope ps(h, PC_GEMM_CHOL, st);
+        const long long o21 = (long long)(j0 + nb) * ldm + j0, o11 = (long long)j0 * ldm + j0;
+        const long long o22 = (long long)(j0 + nb) * ldm + (j0 + nb);
+        // L21 = S21 inv(L11)^T
+        HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_B_KLE_N>(
+                      gargs(Sp + o21, ldm, sM, Lip + o11, ldm, sM, Lp + o21, ldm, sM, rem, nb, nb), B, st)));
+        // S22 -= L21 L21^T, lower tiles, columns of this outer panel only
+        const int nin = J1 - (j0 + nb);
+        if (nin > 0)
             HIPCHK(h, (launch_gemm<true, EPI_NONE, true, TRI_NONE>(
-                          gargs(Lp + oL, ldm, sM, Lp + oL, ldm, sM, Sp + oS, ldm, sM, remo, remo, J1 - J0, -1.0, 1.0),
-                          B, st)));
-        }
+                          gargs(Lp + o21, ldm, sM, Lp + o21, ldm, sM, Sp + o22, ldm, sM, rem, nin, nb, -1.0, 1.0), B, st)));
     }
-    // inv(L) by recursive doubling on the block diagonal:
-    //   inv([[A,0],[Bk,C]]) = [[inv A, 0], [-inv C * Bk * inv A, inv C]]
-    // S's lower part is dead after the factorisation and holds the intermediate Bk * inv A.
-    // The doubling stops at blocks of INV_BS rows: gain_from_factor runs the two triangular solves block-wise with
-    // these diagonal-block inverses, so the levels above (most of the cost of a full inverse) are never built.
+    return 0;
+}
+
+// Li = the inverses of L's diagonal blocks of INV_BS rows (all of inv(L) when ml <= INV_BS) from the inverses of its
+// diagonal NB-blocks, by recursive doubling on the block diagonal:
+//   inv([[A,0],[Bk,C]]) = [[inv A, 0], [-inv C * Bk * inv A, inv C]]
+// S's lower part is dead after the factorisation and holds the intermediate Bk * inv A.
+// The doubling stops at blocks of INV_BS rows: gain_from_factor runs the two triangular solves block-wise with
+// these diagonal-block inverses, so the levels above (most of the cost of a full inverse) are never built.
+int chol_block_inverses(slamk_handle* h, double* Sp, double* Lp, double* Lip, int ldm, long long sM, int B, int ml,
+                        hipStream_t st)
+{
     ProfScope ps_inv(h, PC_GEMM_CHOL, st);
-    for (int s = NB; s < std::min(ml, INV_BS); s *= 2) {
+    for (int s = CHOL_NB; s < std::min(ml, INV_BS); s *= 2) {
         const int nfull = ml / (2 * s), r = ml - nfull * 2 * s;
         for (int pass = 0; pass < 2; ++pass) {
             int cnt, M, base;
@@ -570,19 +562,50 @@ int cholesky_inverse(slamk_handle* h, double* Sp, double* Lp, double* Lip, int l
     return 0;
 }
 
+// S (lower) -> L (Cholesky factor) and Li = the inverses of L's diagonal blocks of INV_BS rows (all of inv(L) when
+// ml <= INV_BS); S is used as scratch afterwards.
+int cholesky_inverse(slamk_handle* h, double* Sp, double* Lp, double* Lip, int ldm, long long sM, int B, int ml,
+                     int* status, hipStream_t st)
+{
+    const int OB = chol_outer_block();
+    // Blocked right-looking Cholesky on two levels: inside an outer panel of OB columns the updates are of rank
+    // CHOL_NB and stay inside the panel; the columns right of the panel take one rank-OB update when the panel is
+    // complete, which reads and writes the large trailing matrix OB / CHOL_NB times less often.
+    for (int J0 = 0; J0 < ml; J0 += OB) {
+        const int J1 = std::min(ml, J0 + OB);
+        int rc = chol_outer_panel(h, Sp, Lp, Lip, ldm, sM, B, ml, J0, J1, status, st);
+        if (rc) return rc;
+        const int remo = ml - J1;
+        if (remo > 0) {          // the rest of the trailing matrix: one update of rank J1 - J0
+            ProfScope ps(h, PC_GEMM_CHOL, st);
+            const long long oL = (long long)J1 * ldm + J0, oS = (long long)J1 * ldm + J1;
+            HIPCHK(h, (launch_gemm<true, EPI_NONE, true, TRI_NONE>(
+                          gargs(Lp + oL, ldm, sM, Lp + oL, ldm, sM, Sp + oS, ldm, sM, remo, remo, J1 - J0, -1.0, 1.0),
+                          B, st)));
+        }
+    }
+    return chol_block_inverses(h, Sp, Lp, Lip, ldm, sM, B, ml, st);
+}
+
 // K = W S^-1 = (W L^-T) L^-1 and K R from the factor L and the inverses Li of its diagonal INV_BS-blocks, as two
 // block triangular solves (calcK, src/slam/main.cpp:547-550 solved by Cholesky instead of LU):
 //     Y_j = (W_j - sum_{k<j} Y_k L_jk^T) inv(L_jj)^T,  j ascending;   K_j = (Y_j - sum_{k>j} K_k L_kj) inv(L_jj),  j descending.
 // W (rows x ml) is overwritten; every product is a GEMM with at least min(ml, INV_BS) columns.
+// ws: workspace for cutting the k range of the off-diagonal products into slices (one matrix with few rows, i.e. a row
+// block of a sharded filter); null: never cut.
 int gain_from_factor(slamk_handle* h, double* W, double* Y, double* K, double* KR, int ldw, long long sW,
                      const double* L, const double* Li, int ldl, long long sL, const double* rdiag, long long sR,
-                     int rows, int ml, int B, hipStream_t st)
+                     int rows, int ml, int B, hipStream_t st, double* ws = nullptr, size_t ws_elems = 0)
 {
+    if (B != 1) ws = nullptr;
     const int nbk = (ml + INV_BS - 1) / INV_BS;
     for (int j = 0; j < nbk; ++j) {
         const int c0 = j * INV_BS, wj = std::min(INV_BS, ml - c0);
         const long long odiag = (long long)c0 * ldl + c0;
-        if (j > 0)
+        if (j > 0 && ws)
+            HIPCHK(h, launch_gemm_splitk<true>(gargs(Y, ldw, sW, L + (long long)c0 * ldl, ldl, sL, W + c0, ldw, sW, rows, wj, c0,
+                                                     -1.0, 1.0), ws, ws_elems, st));
+        else if (j > 0)
             HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_NONE>(
                           gargs(Y, ldw, sW, L + (long long)c0 * ldl, ldl, sL, W + c0, ldw, sW, rows, wj, c0, -1.0, 1.0), B, st)));
         HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_B_KLE_N>(
@@ -591,7 +614,10 @@ int gain_from_factor(slamk_handle* h, double* W, double* Y, double* K, double* K
     for (int j = nbk - 1; j >= 0; --j) {
         const int c0 = j * INV_BS, wj = std::min(INV_BS, ml - c0), c1 = c0 + wj;
         const long long odiag = (long long)c0 * ldl + c0;
-        if (c1 < ml)
+        if (c1 < ml && ws)
+            HIPCHK(h, launch_gemm_splitk<false>(gargs(K + c1, ldw, sW, L + (long long)c1 * ldl + c0, ldl, sL, Y + c0, ldw, sW, rows,
+                                                      wj, ml - c1, -1.0, 1.0), ws, ws_elems, st));
+        else if (c1 < ml)
             HIPCHK(h, (launch_gemm<false, EPI_NONE, false, TRI_NONE>(
                           gargs(K + c1, ldw, sW, L + (long long)c1 * ldl + c0, ldl, sL, Y + c0, ldw, sW, rows, wj, ml - c1, -1.0,
                                 1.0), B, st)));
@@ -1738,14 +1764,16 @@ int slamk_cholesky_inverse_dev(double* S_dev, double* L_dev, double* Li_dev, int
 }
 
 // ---- one large-map filter sharded by row blocks over the GPUs of a node ------------------------------------
-// Rank r owns rows [r bn, (r + 1) bn) of P and of every n-row product (T = P F^T, W = P H^T, K, A) and rows
-// [r bm, (r + 1) bm) of S.  The O(nf) filter state is replicated: every rank runs the per-feature kernels itself and
-// holds the compact rows of F and H, so the products with the Jacobians are local sweeps over the rank's row block and
-// the only traffic is one all-gather per dense contraction (RCCL over xGMI, in place, on the caller's stream):
-//     predict:  T_r = P_r F^T -> all-gather T -> P_r = F_r T + Q_r                      (calcP, main.cpp:526-530)
-//     update :  W_r = P_r H^T -> all-gather W -> S_q = H_q W + R_q -> all-gather S      (calcK, :539-552)
-//               S = L L^T and the inverses of L's diagonal blocks (replicated)
-//               K_r = W_r L^-T L^-1 -> all-gather K;  A_r = I_r - K_r H -> all-gather A, all-gather P
+// Rank r owns rows [r bn, (r + 1) bn) of P and of every n-row product (T = P F^T, W = P H^T, K).  The O(nf) filter
+// state is replicated: every rank runs the per-feature kernels itself and holds the compact rows of F and H, so the
+// products with the Jacobians are local sweeps and the traffic is one all-gather per dense contraction (RCCL over
+// xGMI, in place, on the caller's stream):
+//     predict:  T_r = P_r F^T -> all-gather of the few rows of T other ranks read -> P_r = F_r T + Q_r
+//                                                                                       (calcP, main.cpp:526-530)
+//     update :  W_r = P_r H^T -> all-gather W                                           (calcK, :539-552)
+//               S = H W + R = L L^T, left-looking by panels of columns: every rank forms and updates an equal share
+//               of the rows of the panel, all-gather of the panel, panel factorisation on every rank
+//               K_r = W_r L^-T L^-1 -> all-gather K;  A = I - K H (every rank, from the gathered K); all-gather P
 //               P_r <- (A_r P) A^T + (K_r R) K^T                                        (Joseph form of updateP, :561-569)
 //               dx = K e, gate, mean update (replicated)                                (:228-232)
 struct RcclApi {
@@ -1783,17 +1811,52 @@ struct slamk_sharded {
     slamk_allgather_fn ag = nullptr;
     void* ag_ctx = nullptr;
     int n = 0, m = 0, bn = 0, bm = 0, N = 0, M = 0, r0 = 0, q0 = 0;
-    double *P = nullptr, *G1 = nullptr, *G2 = nullptr, *Ar = nullptr, *AP = nullptr, *W = nullptr, *K = nullptr, *Y = nullptr,
-           *KR = nullptr, *S = nullptr, *Lm = nullptr, *Li = nullptr, *rfull = nullptr;
+    double *P = nullptr, *G1 = nullptr, *G2 = nullptr, *AP = nullptr, *W = nullptr, *K = nullptr, *Y = nullptr,
+           *KR = nullptr, *S = nullptr, *Lm = nullptr, *Li = nullptr, *rfull = nullptr, *U = nullptr, *halo = nullptr, *ws = nullptr;
+    size_t U_elems = 0, ws_elems = 0;
     std::vector<void*> allocs;
 };
 
-// rows [lo, hi) of the padded S: zero with a unit diagonal (rows the measurement operator does not have)
-__global__ void pad_identity_rows_kernel(double* __restrict__ S, int ld, int lo, int hi)
+// rows [lo, hi) of S inside a panel buffer whose first column is column `col0` of S and whose row 0 is row `lo`:
+// zero with a unit diagonal (rows the measurement operator does not have)
+__global__ void pad_identity_rows_kernel(double* __restrict__ U, int ld, int cols, int col0, int lo, int hi)
 {
     const int r = lo + blockIdx.y;
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (r < hi && c < ld) S[(long long)r * ld + c] = (c == r) ? 1.0 : 0.0;
+    if (r < hi && c < cols) U[(long long)(r - lo) * ld + c] = (c + col0 == r) ? 1.0 : 0.0;
+}
+
+// The rows of T = P F^T that a rank other than their owner reads in P_r = F_r T + Q_r (motion_row,
+// structured_kernels.hip.h): rows 0..5 (position and velocity: every row of F has entries on columns 3..5, the position
+// rows and rows without a second group on columns 0..2), the bias triple (velocity rows) and, because a feature's
+// triple may lie across a block boundary, the first and the last two rows of every block.
+constexpr int HALO_ROWS = 13;
+__device__ __forceinline__ int halo_row(int t, int p, int bn, int bias0)
+{
+    // global row of slot t in the pack of rank p, or -1 when that rank does not own the slot's row
+    int row;
+    if (t < 2) row = p * bn + t;
+    else if (t < 4) row = (p + 1) * bn - 4 + t;
+    else if (t < 10) row = t - 4;
+    else row = bias0 + t - 10;
+    if (row < p * bn || row >= (p + 1) * bn) return -1;
+    return row;
+}
+// grid (ceil(N / 256), HALO_ROWS): this rank's slots of T (rows at their global position in G) -> its pack
+__global__ void halo_pack_kernel(const double* __restrict__ G, double* __restrict__ pack, int N, int rank, int bn, int bias0)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y;
+    if (c >= N) return;
+    const int row = halo_row(t, rank, bn, bias0);
+    pack[((long long)rank * HALO_ROWS + t) * N + c] = row < 0 ? 0.0 : G[(long long)row * N + c];
+}
+// grid (ceil(N / 256), HALO_ROWS, world): the gathered packs -> rows of G at their global position
+__global__ void halo_unpack_kernel(double* __restrict__ G, const double* __restrict__ pack, int N, int rank, int bn, int bias0)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y, p = blockIdx.z;
+    if (c >= N || p == rank) return;
+    const int row = halo_row(t, p, bn, bias0);
+    if (row >= 0) G[(long long)row * N + c] = pack[((long long)p * HALO_ROWS + t) * N + c];
 }
 __global__ void fill_kernel(double* __restrict__ x, int n, double v)
 {
@@ -1905,10 +1968,15 @@ int slamk_sharded_load_cov_dev(slamk_sharded* s, const double* P_full_dev, int l
         return 0;
     };
     int rc = 0;
-    rc |= alloc(&s->P, bn * N); rc |= alloc(&s->G1, N * N); rc |= alloc(&s->G2, N * N); rc |= alloc(&s->Ar, bn * N);
+    // U: one panel of S, the rows from its diagonal block down dealt to the ranks in equal padded shares
+    s->U_elems = (M + 16 * (size_t)g) * std::min<size_t>(M, chol_outer_block());
+    rc |= alloc(&s->P, bn * N); rc |= alloc(&s->G1, N * N); rc |= alloc(&s->G2, N * N);
     rc |= alloc(&s->AP, bn * N); rc |= alloc(&s->W, N * M); rc |= alloc(&s->K, N * M); rc |= alloc(&s->Y, bn * M);
     rc |= alloc(&s->KR, bn * M); rc |= alloc(&s->S, M * M); rc |= alloc(&s->Lm, M * M); rc |= alloc(&s->Li, M * M);
-    rc |= alloc(&s->rfull, M);
+    rc |= alloc(&s->rfull, M); rc |= alloc(&s->U, s->U_elems); rc |= alloc(&s->halo, (size_t)g * HALO_ROWS * N);
+    // partial products of the GEMMs whose k range is cut into slices (a rank's rows are few, the k ranges long)
+    s->ws_elems = std::max(8 * (s->U_elems / g), 4 * bn * std::min<size_t>(M, INV_BS));
+    rc |= alloc(&s->ws, s->ws_elems);
     if (rc) { sharded_free(s); return SLAMK_EHIP; }
     const int hi = std::min(n, s->r0 + s->bn);
     if (hi > s->r0)
@@ -1925,9 +1993,65 @@ int slamk_sharded_predict_dev(slamk_sharded* s, const double* qbw_dev, const dou
     hipStream_t st = (hipStream_t)stream;
     int rc = slamk_stage_motion_dev(h, qbw_dev, w_dev, acc_dev, dt_dev, stream);
     if (!rc) rc = slamk_stage_right_dev(h, 0, s->P, s->N, s->bn, s->G1 + (size_t)s->r0 * s->N, s->N, stream);   // T_r = P_r F^T
-    if (!rc) { ENTER(h); rc = sharded_allgather(s, s->G1, (size_t)s->bn * s->N, st); }
-    if (!rc) rc = slamk_stage_left_dev(h, 0, s->r0, s->bn, s->G1, s->N, s->N, s->P, s->N, 1, stream);          // P_r = F_r T + Q_r
-    return rc;
+    if (rc) return rc;
+    ENTER(h);
+    if (s->world > 1 || s->comm) {       // the rows of T that ranks other than their owner read
+        const int bias0 = 6 + 3 * h->hf[0].nf;
+        hipLaunchKernelGGL(halo_pack_kernel, dim3((s->N + 255) / 256, HALO_ROWS), dim3(256), 0, st, s->G1, s->halo, s->N,
+                           s->rank, s->bn, bias0);
+        HIPCHK(h, hipGetLastError());
+        rc = sharded_allgather(s, s->halo, (size_t)HALO_ROWS * s->N, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(halo_unpack_kernel, dim3((s->N + 255) / 256, HALO_ROWS, s->world), dim3(256), 0, st, s->G1,
+                           s->halo, s->N, s->rank, s->bn, bias0);
+        HIPCHK(h, hipGetLastError());
+    }
+    return slamk_stage_left_dev(h, 0, s->r0, s->bn, s->G1, s->N, s->N, s->P, s->N, 1, stream);                  // P_r = F_r T + Q_r
+}
+
+// S = H W + R = L L^T and the inverses of L's diagonal blocks, every rank ending with the whole factor.  Left-looking
+// by panels of chol_outer_block() columns: the rows of panel [J0, J1) from its diagonal block down are dealt to the ranks
+// in equal shares; a rank forms its rows of S from the gathered W and the compact rows of H (S as a whole never
+// exists), subtracts L[rows, 0:J0] L[J0:J1, 0:J0]^T, the panel is all-gathered and factored on every rank (diagonal blocks,
+// L21, rank-CHOL_NB updates inside the panel).  Per rank m^3 / (3 world) of the m^3 / 3 FLOP of the trailing updates.
+static int sharded_cholesky(slamk_sharded* s, hipStream_t st)
+{
+    slamk_handle* h = s->h;
+    const int M = s->M, g = s->world, OB = chol_outer_block();
+    const int mrows = std::min(max_ml(h), M);          // rows the measurement operator has
+    for (int J0 = 0; J0 < M; J0 += OB) {
+        const int J1 = std::min(M, J0 + OB), ob = J1 - J0, R = M - J0;
+        const int chunk = pad16((R + g - 1) / g);
+        if ((size_t)g * chunk * ob > s->U_elems)
+            return fail(h, SLAMK_EINVAL, "sharded: the block sizes changed since the covariance was loaded");
+        const int row0 = J0 + s->rank * chunk, rows = std::max(0, std::min(M, row0 + chunk) - row0);
+        double* Ur = s->U + (size_t)s->rank * chunk * ob;
+        if (rows > 0) {
+            const int rop = std::max(0, std::min(rows, mrows - row0));
+            if (rop) {
+                RowSparse Hs{h->fv.ha + 3 * (size_t)row0, h->fv.hb + 3 * (size_t)row0, h->fv.hcs + row0, h->ldm, 0};
+                hipLaunchKernelGGL(rowsparse_left_kernel<false>,
+                                   dim3((ob + 63) / 64, (rop + 4 * STRUCT_RPW - 1) / (4 * STRUCT_RPW), 1), dim3(256), 0, st, Hs,
+                                   s->W + J0, M, 0LL, Ur, ob, 0LL, h->fv.rdiag + row0, 0LL, rop, ob, STRUCT_RPW, row0 - J0);
+            }
+            if (rop < rows)
+                hipLaunchKernelGGL(pad_identity_rows_kernel, dim3((ob + 255) / 256, rows - rop), dim3(256), 0, st,
+                                   Ur + (size_t)rop * ob, ob, ob, J0, row0 + rop, row0 + rows);
+            HIPCHK(h, hipGetLastError());
+            if (J0 > 0) {
+                ProfScope ps(h, PC_GEMM_CHOL, st);
+                HIPCHK(h, launch_gemm_splitk<true>(gargs(s->Lm + (size_t)row0 * M, M, 0, s->Lm + (size_t)J0 * M, M, 0, Ur, ob, 0,
+                                                         rows, ob, J0, -1.0, 1.0), s->ws, s->ws_elems, st));
+            }
+        }
+        int rc = sharded_allgather(s, s->U, (size_t)chunk * ob, st);
+        if (rc) return rc;
+        HIPCHK(h, hipMemcpy2DAsync(s->S + (size_t)J0 * M + J0, (size_t)M * sizeof(double), s->U, (size_t)ob * sizeof(double),
+                                   (size_t)ob * sizeof(double), R, hipMemcpyDeviceToDevice, st));
+        rc = chol_outer_panel(h, s->S, s->Lm, s->Li, M, 0, 1, M, J0, J1, h->fv.status, st);
+        if (rc) return rc;
+    }
+    return chol_block_inverses(h, s->S, s->Lm, s->Li, M, 0, 1, M, st);
 }
 
 int slamk_sharded_update_dev(slamk_sharded* s, const double* qbw_dev, const double* alt_dev, const double* src_dev,
@@ -1936,41 +2060,31 @@ int slamk_sharded_update_dev(slamk_sharded* s, const double* qbw_dev, const doub
     { int rc = sharded_check(s); if (rc) return rc; }
     slamk_handle* h = s->h;
     hipStream_t st = (hipStream_t)stream;
-    const size_t N = s->N, M = s->M, bn = s->bn, bm = s->bm, r0 = s->r0, q0 = s->q0;
+    const size_t N = s->N, M = s->M, bn = s->bn, r0 = s->r0;
     int rc = slamk_stage_measure_dev(h, qbw_dev, alt_dev, src_dev, refl_dev, stream);
     if (rc) return rc;
     ENTER(h);
     rc = slamk_stage_right_dev(h, 1, s->P, s->N, s->bn, s->W + r0 * M, s->M, stream);                          // W_r = P_r H^T
     if (!rc) rc = sharded_allgather(s, s->W, bn * M, st);
-    if (!rc) rc = slamk_stage_left_dev(h, 1, s->q0, s->bm, s->W, s->M, s->M, s->S + q0 * M, s->M, 1, stream);  // S_q = H_q W + R_q
     if (rc) return rc;
     // diagonal of R over the padded measurement rows: the operator's own rows, 1 beyond them
     const int ml = std::min(max_ml(h), s->M);
     hipLaunchKernelGGL(fill_kernel, dim3((s->M + 255) / 256), dim3(256), 0, st, s->rfull, s->M, 1.0);
     HIPCHK(h, hipMemcpyAsync(s->rfull, h->fv.rdiag, (size_t)ml * sizeof(double), hipMemcpyDeviceToDevice, st));
-    const int lo = std::max(s->q0, ml), hi = s->q0 + s->bm;
-    if (lo < hi)
-        hipLaunchKernelGGL(pad_identity_rows_kernel, dim3((s->M + 255) / 256, hi - lo), dim3(256), 0, st, s->S, s->M, lo, hi);
-    HIPCHK(h, hipGetLastError());
-    rc = sharded_allgather(s, s->S, bm * M, st);
-    if (rc) return rc;
-    // S = L L^T and the inverses of L's diagonal blocks, on every rank (S is scratch afterwards)
     HIPCHK(h, hipMemsetAsync(s->Lm, 0, M * M * sizeof(double), st));
     HIPCHK(h, hipMemsetAsync(s->Li, 0, M * M * sizeof(double), st));
-    rc = cholesky_inverse(h, s->S, s->Lm, s->Li, s->M, 0, 1, s->M, h->fv.status, st);
-    if (!rc) rc = slamk_stage_gain_dev(h, s->W + r0 * M, s->bn, s->M, s->M, s->Lm, s->Li, s->M, s->Y, s->K + r0 * M, s->KR,
-                                       s->rfull, stream);                                                      // K_r, K_r R
+    rc = sharded_cholesky(s, st);
+    if (!rc) rc = gain_from_factor(h, s->W + r0 * M, s->Y, s->K + r0 * M, s->KR, s->M, 0, s->Lm, s->Li, s->M, 0, s->rfull, 0,
+                                   s->bn, s->M, 1, st, s->ws, s->ws_elems);                                    // K_r, K_r R
     if (!rc) rc = sharded_allgather(s, s->K, bn * M, st);
-    if (!rc) rc = slamk_stage_eye_minus_kh_dev(h, s->K + r0 * M, s->M, s->r0, s->bn, s->Ar, s->N, stream);      // A_r = I_r - K_r H
-    if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(s->G2 + r0 * N, s->Ar, bn * N * sizeof(double), hipMemcpyDeviceToDevice, st));
-    rc = sharded_allgather(s, s->G2, bn * N, st);
+    if (!rc) rc = slamk_stage_eye_minus_kh_dev(h, s->K, s->M, 0, s->N, s->G2, s->N, stream);                    // A = I - K H
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(s->G1 + r0 * N, s->P, bn * N * sizeof(double), hipMemcpyDeviceToDevice, st));
     rc = sharded_allgather(s, s->G1, bn * N, st);
     if (rc) return rc;
+    const double* Ar = s->G2 + r0 * N;
     // P_r <- (A_r P) A^T + (K_r R) K^T
-    HIPCHK(h, (launch_gemm<false, EPI_NONE, false, TRI_NONE>(gargs(s->Ar, s->N, 0, s->G1, s->N, 0, s->AP, s->N, 0, s->bn, s->N, s->N), 1, st)));
+    HIPCHK(h, (launch_gemm<false, EPI_NONE, false, TRI_NONE>(gargs(Ar, s->N, 0, s->G1, s->N, 0, s->AP, s->N, 0, s->bn, s->N, s->N), 1, st)));
     HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_NONE>(gargs(s->AP, s->N, 0, s->G2, s->N, 0, s->P, s->N, 0, s->bn, s->N, s->N), 1, st)));
     HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_NONE>(gargs(s->KR, s->M, 0, s->K, s->M, 0, s->P, s->N, 0, s->bn, s->N, s->M, 1.0, 1.0), 1, st)));
     return slamk_stage_apply_dev(h, s->K, s->M, applied_dev, stream);                                           // dx = K e, gate

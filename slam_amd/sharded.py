@@ -7,11 +7,12 @@ runs the per-feature kernels itself and holds the compact rows of F and H (at mo
 per row), so the products with the Jacobians are local, bandwidth-bound sweeps over the rank's row
 block and the only traffic is one all-gather per dense contraction:
 
-    predict:  T_r = P_r F^T                    -> all-gather T ->  P_r = F_r T + Q_r
-    update :  W_r = P_r H^T                    -> all-gather W ->  S_q = H_q W + R_q   -> all-gather S
-              L L^T = S, Li = inverses of L's diagonal blocks   (replicated: the part that does not scale)
-              K_r = W_r L^-T L^-1              -> all-gather K
-              A_r = I_r - K_r H                -> all-gather A, all-gather P
+    predict:  T_r = P_r F^T  -> all-gather of the 13 rows of T per rank that other ranks read ->  P_r = F_r T + Q_r
+    update :  W_r = P_r H^T  -> all-gather W
+              S = H W + R = L L^T, left-looking by panels of columns: each rank forms its share of the rows of the
+              panel from W and the rows of H and subtracts L[rows, :J0] L[J0:J1, :J0]^T -> all-gather of the panel ->
+              panel factorisation on every rank; Li = inverses of L's diagonal blocks
+              K_r = W_r L^-T L^-1      -> all-gather K;   A = I - K H on every rank;   all-gather P
               P_r <- (A_r P) A^T + (K_r R) K^T (Joseph form, row block r; three dense GEMMs)
               dx = K e, gate, mean update      (replicated, every rank holds the full K)
 
@@ -143,12 +144,14 @@ class ShardedFilter:
 
 class ShardedLargeMapFilter:
     """The sequence of the module docstring over a backend object (CPU rehearsal of the sharding; the product path is
-    ShardedFilter)."""
+    ShardedFilter).  `panel`: columns per panel of the factorisation (the library's outer block size)."""
 
     F, H = 0, 1
+    HALO = 13
 
-    def __init__(self, backend, rank=0, world=1, group=None):
+    def __init__(self, backend, rank=0, world=1, group=None, panel=512):
         self.be, self.rank, self.world, self.group = backend, rank, world, group
+        self.panel = panel
         self.n = self.m = 0
         self.P = None
 
@@ -158,9 +161,9 @@ class ShardedLargeMapFilter:
         g = self.world
         self.n, self.m = n, m
         self.bn = _pad16((_pad16(n) + g - 1) // g)      # rows of P per rank
-        self.bm = _pad16((_pad16(m) + g - 1) // g)      # rows of S per rank
+        self.bm = _pad16((_pad16(m) + g - 1) // g)
         self.N, self.M = self.bn * g, self.bm * g       # padded global dimensions
-        self.r0, self.q0 = self.rank * self.bn, self.rank * self.bm
+        self.r0 = self.rank * self.bn
 
     def load_cov(self, P_full):
         """Distribute a full n x n covariance (same on every rank): keep rows [r0, r0 + bn)."""
@@ -170,16 +173,14 @@ class ShardedLargeMapFilter:
         hi = min(self.n, self.r0 + self.bn)
         if hi > self.r0:
             self.P[:hi - self.r0, :self.n] = P_full[self.r0:hi, :self.n]
-        self.G1 = be.empty(self.N, self.N)          # gathered T, then gathered P
-        self.G2 = be.empty(self.N, self.N)          # gathered A
-        self.Ar = be.empty(self.bn, self.N)         # A_r, then (A_r P)
+        self.G1 = be.empty(self.N, self.N)          # T (own rows and the rows received), then gathered P
+        self.G2 = be.empty(self.N, self.N)          # A
         self.AP = be.empty(self.bn, self.N)
         self.W = be.empty(self.N, self.M)
         self.K = be.empty(self.N, self.M)
         self.Y = be.empty(self.bn, self.M)
         self.KR = be.empty(self.bn, self.M)
-        self.S = be.empty(self.M, self.M)
-        self.S2 = be.empty(self.M, self.M)
+        self.S = be.empty(self.M, self.M)           # the panels as they are factored (never S as a whole)
         self.Lm = be.empty(self.M, self.M)
         self.Li = be.empty(self.M, self.M)
         self.rfull = be.empty(1, self.M)[0]
@@ -207,41 +208,72 @@ class ShardedLargeMapFilter:
         return full[:self.n, :self.n]
 
     # -- loop body ---------------------------------------------------------------------------
+    def _halo_rows(self, p):
+        """Global rows of T in the 13 slots of rank p's pack (-1: not owned by p): the first and the last two rows of
+        its block (a feature's triple may lie across a block boundary), rows 0..5 (position, velocity) and the bias
+        triple: everything a row of F outside the block can refer to."""
+        bn, bias0 = self.bn, self.n - 3
+        cand = [p * bn, p * bn + 1, (p + 1) * bn - 2, (p + 1) * bn - 1, 0, 1, 2, 3, 4, 5, bias0, bias0 + 1, bias0 + 2]
+        return [r if p * bn <= r < (p + 1) * bn else -1 for r in cand]
+
     def predict(self, qbw, w, acc, dt):
         be = self.be
         be.motion(qbw, w, acc, dt)
         r = slice(self.r0, self.r0 + self.bn)
         be.right(self.F, self.G1[r], self.P)                        # T_r = P_r F^T
-        self._all_gather(self.G1, self.bn)
+        if self.world > 1:
+            pack = be.empty(self.world * self.HALO, self.N)
+            for t, row in enumerate(self._halo_rows(self.rank)):
+                if row >= 0:
+                    pack[self.rank * self.HALO + t] = self.G1[row]
+            self._all_gather(pack, self.HALO)
+            for p in range(self.world):
+                if p != self.rank:
+                    for t, row in enumerate(self._halo_rows(p)):
+                        if row >= 0:
+                            self.G1[row] = pack[p * self.HALO + t]
         be.left(self.F, self.P, self.r0, self.G1, True)             # P_r = F_r T + Q_r
+
+    def _cholesky(self):
+        """S = H W + R = L L^T, every rank ending with L and the inverses of its diagonal blocks."""
+        be, g, M = self.be, self.world, self.M
+        for J0 in range(0, M, self.panel):
+            J1 = min(M, J0 + self.panel)
+            ob, R = J1 - J0, M - J0
+            chunk = _pad16((R + g - 1) // g)            # rows of the panel per rank
+            U = be.empty(g * chunk, ob)
+            row0 = J0 + self.rank * chunk
+            rows = max(0, min(M, row0 + chunk) - row0)
+            if rows > 0:
+                Ur = U[self.rank * chunk:self.rank * chunk + rows]
+                rop = be.left(self.H, Ur, row0, self.W[:, J0:J1], True, col0=J0)    # rows of H W + R
+                for q in range(row0 + rop, row0 + rows):                           # rows the operator does not have
+                    if J0 <= q < J1:
+                        Ur[q - row0, q - J0] = 1.0
+                if J0 > 0:
+                    be.gemm(Ur, self.Lm[row0:row0 + rows, :J0], self.Lm[J0:J1, :J0], True, alpha=-1.0, beta=1.0)
+            self._all_gather(U, chunk)
+            self.S[J0:M, J0:J1] = U[:R]
+            be.chol_panel(self.S, self.Lm, J0, J1)
+        be.block_inverses(self.Lm, self.Li)
 
     def update(self, qbw, src=None, refl=None):
         be, m = self.be, self.m
         e, rd = be.measure(qbw, src, refl)
         r = slice(self.r0, self.r0 + self.bn)
-        q = slice(self.q0, self.q0 + self.bm)
         be.right(self.H, self.W[r], self.P)                         # W_r = P_r H^T
         self._all_gather(self.W, self.bn)
-        be.left(self.H, self.S[q], self.q0, self.W, True)           # S_q = H_q W + R_q
         ml = min(_pad16(m), rd.shape[0])
         self.rfull.fill_(1.0)                                       # unit diagonal on the rows the operator does not have
         self.rfull[:ml] = rd[:ml]
-        lo, hi = max(self.q0, ml), self.q0 + self.bm
-        if lo < hi:
-            pad = torch.arange(lo, hi, device=self.S.device)
-            self.S[lo:hi] = 0.0
-            self.S[pad, pad] = 1.0
-        self._all_gather(self.S, self.bm)
-        self.S2.copy_(self.S)
         self.Lm.zero_()
         self.Li.zero_()
-        be.cholesky_inverse(self.S2, self.Lm, self.Li)              # replicated
+        self._cholesky()
         be.gain(self.Y, self.K[r], self.KR, self.W[r], self.Lm, self.Li, self.rfull)   # K_r = W_r S^-1, K_r R
         self._all_gather(self.K, self.bn)
-        be.eye_minus_kh(self.Ar, self.K[r], self.r0)                # A_r = I_r - K_r H
-        self._all_gather(self.G2, self.bn, self.Ar)
+        be.eye_minus_kh(self.G2, self.K, 0)                         # A = I - K H, all rows, on every rank
         self._all_gather(self.G1, self.bn, self.P)
-        be.gemm(self.AP, self.Ar, self.G1, False)                   # A_r P
+        be.gemm(self.AP, self.G2[r], self.G1, False)                # A_r P
         be.gemm(self.P, self.AP, self.G2, True)                     # (A_r P) A^T
         be.gemm(self.P, self.KR, self.K, True, alpha=1.0, beta=1.0)  # + (K_r R) K^T
         return be.apply(self.K)                                     # dx = K e, gate, mean update (replicated)

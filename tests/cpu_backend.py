@@ -47,15 +47,20 @@ class OracleBackend:
         M, _ = self._op(which)
         Out[:, :M.shape[0]] = In[:, :M.shape[1]] @ M.T
 
-    def left(self, which, Out, row0, In, add_diag):
+    def left(self, which, Out, row0, In, add_diag, col0=0):
+        """Out = M[row0:row0 + rows] In (+ the diagonal term where its column row - col0 lies inside Out); returns the
+        number of rows the operator has in this range."""
         M, d = self._op(which)
         rows = max(0, min(Out.shape[0], M.shape[0] - row0))
         if rows == 0:
-            return
+            return 0
         Out[:rows] = M[row0:row0 + rows] @ In[:M.shape[1]]
         if add_diag:
-            idx = torch.arange(rows)
-            Out[idx, row0 + idx] += d[row0:row0 + rows]
+            for i in range(rows):
+                c = row0 + i - col0
+                if 0 <= c < Out.shape[1]:
+                    Out[i, c] += d[row0 + i]
+        return rows
 
     def eye_minus_kh(self, A, K, row0):
         n, m = self.dims()
@@ -76,10 +81,15 @@ class OracleBackend:
         else:
             Cm.mul_(beta).add_(alpha * prod)
 
-    def cholesky_inverse(self, S, Lm, Li):
-        L = torch.linalg.cholesky(S)
-        Lm.copy_(L)
-        Li.copy_(torch.linalg.solve_triangular(L, torch.eye(S.shape[0], dtype=torch.float64), upper=False))
+    def chol_panel(self, S, Lm, J0, J1):
+        """Columns [J0, J1) of the factor from the same columns of S, which carry the updates of the columns before."""
+        L11 = torch.linalg.cholesky(S[J0:J1, J0:J1])
+        Lm[J0:J1, J0:J1] = L11
+        if J1 < S.shape[0]:
+            Lm[J1:, J0:J1] = torch.linalg.solve_triangular(L11, S[J1:, J0:J1].T, upper=False).T
+
+    def block_inverses(self, Lm, Li):
+        Li.copy_(torch.linalg.solve_triangular(Lm, torch.eye(Lm.shape[0], dtype=torch.float64), upper=False))
 
     def apply(self, K):
         n, m = self.dims()

@@ -586,10 +586,12 @@ def test_full_size_batch_properties():
         assert np.linalg.eigvalsh(P).min() > 0
 
 
-def _run_sharded(rank, world, group, nf, steps, dev, rccl_single_rank=False):
-    """The stream of the sharded tests through slamk_sharded_* on this rank; returns (P, state vector)."""
+def _run_sharded(rank, world, group, nf, steps, dev, rccl_single_rank=False, blocks=None):
+    """The stream of the sharded tests through slamk_sharded_* on this rank; returns (P, state vector).
+    blocks: (outer panel columns, rows of the inverse blocks) for this run."""
     import torch
     from slam_amd.sharded import ShardedFilter
+    ekf.set_block_sizes(*(blocks or (512, 4096)))
     st = synth.gen_stream(seed=17, nf=nf, steps=steps, churn=False)
     inp = helpers.stream_inputs(st, 7)
     fb = ekf.FilterBatch(max_features=nf, batch=1)
@@ -618,32 +620,34 @@ def _run_sharded(rank, world, group, nf, steps, dev, rccl_single_rank=False):
     out = P.cpu().numpy(), fb.state_vector(0), applied, sh.dims()
     sh.close()
     fb.close()
+    if blocks:
+        ekf.set_block_sizes(512, 4096)
     return out
 
 
-@pytest.mark.parametrize("rccl", [False, True])
-def test_sharded_filter_single_rank(rccl):
+@pytest.mark.parametrize("rccl,blocks", [(False, None), (True, None), (True, (128, 128))])
+def test_sharded_filter_single_rank(rccl, blocks):
     """slamk_sharded_* with one rank (the same products and stage calls as with more ranks) against the oracle; with
     `rccl` the library builds a one-rank RCCL communicator and its all-gathers really go through ncclAllGather."""
     torch = _torch()
     nf, steps = 45, 7
     st = synth.gen_stream(seed=17, nf=nf, steps=steps, churn=False)
     so, f = helpers.run_oracle(st)
-    P, sv, applied, dims = _run_sharded(0, 1, None, nf, steps, torch.device("cuda", 0), rccl_single_rank=rccl)
+    P, sv, applied, dims = _run_sharded(0, 1, None, nf, steps, torch.device("cuda", 0), rccl_single_rank=rccl, blocks=blocks)
     assert applied == [s["applied"] for s in so if s["applied"] >= 0]
     assert helpers.rel_err(P, f.P) < TOL and helpers.entry_err(P, f.P) < TOL
     assert helpers.rel_err(sv, f.state_vector()) < TOL
     assert dims["n"] == 9 + 3 * nf and dims["rows_per_rank"] == dims["n_padded"]
 
 
-def _sharded_worker(rank, world, port, nf, steps, out):
+def _sharded_worker(rank, world, port, nf, steps, out, blocks=None):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        P, sv, applied, dims = _run_sharded(rank, world, None, nf, steps, torch.device("cuda", 0))
+        P, sv, applied, dims = _run_sharded(rank, world, None, nf, steps, torch.device("cuda", 0), blocks=blocks)
         assert dims["rows_per_rank"] * world == dims["n_padded"]
         if rank == world - 1:
             np.save(out, np.concatenate([P.ravel(), sv]))
@@ -651,16 +655,23 @@ def _sharded_worker(rank, world, port, nf, steps, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_filter_several_ranks_on_one_gpu(tmp_path, world):
+@pytest.mark.parametrize("world,nf,blocks", [(2, 45, None), (3, 45, None), (2, 90, (128, 128)), (3, 100, (128, 256))])
+def test_sharded_filter_several_ranks_on_one_gpu(tmp_path, world, nf, blocks):
     """Two and three ranks of slamk_sharded_*, all on GPU 0, the library's all-gathers routed through its callback
-    (gloo, staged through the host): row blocks with row0 > 0, padding rows in the last block, against the oracle."""
+    (gloo, staged through the host): row blocks with row0 > 0, padding rows in the last block, against the oracle.
+    With 128-column panels the factorisation of S takes four panels, each dealt to the ranks by rows, all-gathered
+    and factored on every rank, and the triangular solves take several block steps."""
     import socket
     import torch.multiprocessing as mp
-    nf, steps = 45, 7
+    steps = 7 if nf < 60 else 5
+    if blocks:
+        os.environ["SLAMK_SPLITK_MIN_SLICE"] = "32"      # the products with a long k range run in slices at this size too
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     out = str(tmp_path / "res.npy")
-    mp.spawn(_sharded_worker, args=(world, port, nf, steps, out), nprocs=world, join=True)
+    try:
+        mp.spawn(_sharded_worker, args=(world, port, nf, steps, out, blocks), nprocs=world, join=True)
+    finally:
+        os.environ.pop("SLAMK_SPLITK_MIN_SLICE", None)
     res = np.load(out)
     st = synth.gen_stream(seed=17, nf=nf, steps=steps, churn=False)
     so, f = helpers.run_oracle(st)

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, nf, steps, out):
+def _worker(rank, world, port, nf, steps, panel, out):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -39,7 +39,7 @@ def _worker(rank, world, port, nf, steps, out):
         f.X = st.init_pos
         be = OracleBackend(f)
         be.frame(inp[0][5], inp[0][1])
-        sh = ShardedLargeMapFilter(be, rank, world)
+        sh = ShardedLargeMapFilter(be, rank, world, panel=panel)
         sh.load_cov(torch.from_numpy(f.P))
         for k in range(1, steps):
             u, quat, ang, acc, dt, matches = inp[k]
@@ -55,14 +55,16 @@ def _worker(rank, world, port, nf, steps, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nf", [(2, 7), (2, 13), (3, 10)])
-def test_sharded_matches_oracle(tmp_path, world, nf):
+@pytest.mark.parametrize("world,nf,panel", [(2, 7, 512), (2, 13, 16), (3, 10, 32), (3, 11, 16)])
+def test_sharded_matches_oracle(tmp_path, world, nf, panel):
+    """panel < m: several panels in the left-looking factorisation (rows of a panel dealt to the ranks, all-gather per
+    panel); block boundaries that cut a feature's row triple (the rows of T exchanged in the propagation)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers
     from slam_amd import synth
     steps = 8
     out = str(tmp_path / "res.npy")
-    mp.spawn(_worker, args=(world, _free_port(), nf, steps, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), nf, steps, panel, out), nprocs=world, join=True)
     res = np.load(out)
     st = synth.gen_stream(seed=11, nf=nf, steps=steps, churn=False)
     so, f = helpers.run_oracle(st)
