@@ -247,10 +247,14 @@ int slamk_sharded_create(slamk_handle* h, int rank, int world, const void* nccl_
                          slamk_sharded** out);
 int slamk_sharded_destroy(slamk_sharded* s);
 /* Distributes a full n x n covariance (device memory, the same on every rank): keeps this rank's rows and allocates
- * the rank's workspaces for the current feature set (call again after the feature set changes). */
+ * the rank's workspaces for the current feature set and block sizes (call again after the feature set or
+ * slamk_set_block_sizes changes). */
 int slamk_sharded_load_cov_dev(slamk_sharded* s, const double* P_full_dev, int ld, void* stream);
 int slamk_sharded_predict_dev(slamk_sharded* s, const double* qbw_dev, const double* w_dev, const double* acc_dev,
                               const double* dt_dev, void* stream);
+/* All-gathers per call: W (n x m), every panel of S = H W + R as it is factored (m^2 / 2 doubles in all: the rows of a
+ * panel are formed and updated by the ranks in equal shares, then factored on every rank), K (n x m), P (n x n).
+ * slamk_sharded_predict_dev gathers 13 rows of P F^T per rank. */
 int slamk_sharded_update_dev(slamk_sharded* s, const double* qbw_dev, const double* alt_dev, const double* src_dev,
                              const double* refl_dev, int32_t* applied_dev, void* stream);
 /* The full n x n covariance on every rank (one all-gather). */
