@@ -283,8 +283,8 @@ def large_map(torch, dev, nf=2000, iters=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch-per-gpu", type=int, default=0, help="default: 4096 on one GPU, 8192 on several")
     ap.add_argument("--nf", type=int, default=32)
     ap.add_argument("--groups", type=int, default=1, help="ranges of the batch pipelined on streams of their own")

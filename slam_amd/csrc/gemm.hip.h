@@ -227,12 +227,27 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmArgs g)
     }
 }
 
-// Host-side launcher.  Picks 128x128 tiles for large problems and 64x64 for small ones.
+// Host-side launcher.  64 x 64 tiles unless 128 x 128 tiles are expected to be faster:
+//  - products that skip tiles (LOWER) or trim their k range (TRI) skip and trim at tile granularity, and measured faster
+//    with the small tile at every size up to 10016;
+//  - a plain product with the large tile runs about 5 % faster per FLOP, but only when its tile count fills the
+//    512 workgroup slots of the GPU (2 per CU) evenly: 752 x 6016 is 282 large tiles, about half a round, against
+//    1128 small ones.  The choice compares the two fill fractions.
+// SLAMK_GEMM_BIG_MIN (0: never the large tile) overrides the smallest dimension that may take the large tile.
 template <bool TB, int EPI, bool LOWER, int TRI>
 inline hipError_t launch_gemm(const GemmArgs& g, int batch, hipStream_t stream)
 {
     if (g.M <= 0 || g.N <= 0 || batch <= 0) return hipSuccess;
-    const bool big = (g.M >= 512 && g.N >= 512);
+    static const int big_min = [] { const char* e = getenv("SLAMK_GEMM_BIG_MIN"); return e ? atoi(e) : 512; }();
+    bool big = false;
+    if (!LOWER && TRI == TRI_NONE && big_min > 0 && g.M >= big_min && g.N >= big_min) {
+        auto fill = [&](int t) {
+            const long long tiles = (long long)((g.M + t - 1) / t) * ((g.N + t - 1) / t) * batch;
+            const long long slots = 512;
+            return (double)tiles / (double)((tiles + slots - 1) / slots * slots);
+        };
+        big = fill(128) > 0.95 * fill(64);
+    }
     if (big) {
         dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, batch);
         hipLaunchKernelGGL((gemm_f64_kernel<128, 128, TB, EPI, LOWER, TRI>), grid, dim3(256), 0, stream, g);
@@ -267,12 +282,10 @@ inline int splitk_parts(int M, int N, int K, size_t ws_elems)
 {
     const char* e = getenv("SLAMK_SPLITK_MIN_SLICE");
     const int min_slice = e ? std::max(16, atoi(e)) : 512;
-    const bool big = (M >= 512 && N >= 512);
-    const int t = big ? 128 : 64;
-    const long long tiles = (long long)((M + t - 1) / t) * ((N + t - 1) / t);
-    if (tiles >= 200 || K < 4 * min_slice) return 1;
+    const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);       // a product this small takes 64 x 64 tiles
+    if (tiles >= 400 || K < 4 * min_slice) return 1;
     int parts = 8;
-    while (parts > 1 && (tiles * parts > 1024 || K / parts < min_slice || K % (16 * parts) != 0 ||
+    while (parts > 1 && (tiles * parts > 2048 || K / parts < min_slice || K % (16 * parts) != 0 ||
                          (size_t)parts * M * N > ws_elems))
         parts /= 2;
     return parts;
