@@ -234,20 +234,23 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmArgs g)
 //    512 workgroup slots of the GPU (2 per CU) evenly: 752 x 6016 is 282 large tiles, about half a round, against
 //    1128 small ones.  The choice compares the two fill fractions.
 // SLAMK_GEMM_BIG_MIN (0: never the large tile) overrides the smallest dimension that may take the large tile.
+inline bool gemm_big_tile(int M, int N, int batch, bool lower, int tri)
+{
+    static const int big_min = [] { const char* e = getenv("SLAMK_GEMM_BIG_MIN"); return e ? atoi(e) : 512; }();
+    if (lower || tri != TRI_NONE || big_min <= 0 || M < big_min || N < big_min) return false;
+    auto fill = [&](int t) {
+        const long long tiles = (long long)((M + t - 1) / t) * ((N + t - 1) / t) * batch;
+        const long long slots = 512;
+        return (double)tiles / (double)((tiles + slots - 1) / slots * slots);
+    };
+    return fill(128) > 0.95 * fill(64);
+}
+
 template <bool TB, int EPI, bool LOWER, int TRI>
 inline hipError_t launch_gemm(const GemmArgs& g, int batch, hipStream_t stream)
 {
     if (g.M <= 0 || g.N <= 0 || batch <= 0) return hipSuccess;
-    static const int big_min = [] { const char* e = getenv("SLAMK_GEMM_BIG_MIN"); return e ? atoi(e) : 512; }();
-    bool big = false;
-    if (!LOWER && TRI == TRI_NONE && big_min > 0 && g.M >= big_min && g.N >= big_min) {
-        auto fill = [&](int t) {
-            const long long tiles = (long long)((g.M + t - 1) / t) * ((g.N + t - 1) / t) * batch;
-            const long long slots = 512;
-            return (double)tiles / (double)((tiles + slots - 1) / slots * slots);
-        };
-        big = fill(128) > 0.95 * fill(64);
-    }
+    const bool big = gemm_big_tile(g.M, g.N, batch, LOWER, TRI);
     if (big) {
         dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, batch);
         hipLaunchKernelGGL((gemm_f64_kernel<128, 128, TB, EPI, LOWER, TRI>), grid, dim3(256), 0, stream, g);

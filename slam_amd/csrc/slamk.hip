@@ -957,7 +957,7 @@ int step_launch(slamk_handle* h, const double* qbw_dev, const double* w_dev, con
 // included, zero padding inside edge tiles excluded)
 double gemm_flops(int M, int N, int K, bool lower, int tri)
 {
-    const bool big = (M >= 512 && N >= 512);
+    const bool big = gemm_big_tile(M, N, 1, lower, tri);
     const int BM = big ? 128 : 64, BN = BM;
     double f = 0;
     for (int m0 = 0; m0 < M; m0 += BM)
