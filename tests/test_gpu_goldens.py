@@ -77,6 +77,57 @@ def test_large_map_2000_features_against_golden():
     fb.close()
 
 
+def test_large_map_2000_features_row_block_sharded_against_golden():
+    """configs[3] through slamk_sharded_* at full size (one rank, its all-gathers made on a one-rank RCCL
+    communicator): the left-looking panel factorisation with twenty panels, the products whose k range is cut into
+    slices at their real sizes, the row-block Joseph update; same golden values as the unsharded path."""
+    import torch
+    from slam_amd.sharded import ShardedFilter
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    g = dict(np.load(os.path.join(G, "large_map_nf2000.npz"), allow_pickle=False))
+    fx = helpers.FixtureStream(os.path.join(G, "large_map_nf2000.npz"))
+    nf = 2000
+    fb = ekf.FilterBatch(max_features=nf, batch=1)
+    fb.set_state(0, X=fx.init_pos)
+    u, quat, ang, acc, dt, matches = fx.inp[0]
+    fb.frame(0, matches, quat)
+    stream = torch.cuda.Stream(device=dev)
+    sh = ShardedFilter(fb, 0, 1, None, device=dev, stream=stream, rccl_single_rank=True)
+    P0 = torch.from_numpy(fb.get_cov(0)).to(dev)
+    torch.cuda.synchronize()
+    sh.load_cov(P0)
+    t = lambda v: torch.tensor(np.asarray(v, dtype=np.float64), device=dev)
+    si, sj = g["sample_i"], g["sample_j"]
+    worst = 0.0
+    for k in range(1, len(fx.inp)):
+        u, quat, ang, acc, dt, matches = fx.inp[k]
+        fb.frame(0, matches, quat)
+        q, w, a, d_ = t(quat), t(ang), t(acc), t([dt])
+        torch.cuda.synchronize()
+        sh.predict(q, w, a, d_)
+        ap = sh.update(q)
+        sh.sync()
+        assert int(ap.item()) == int(g["applied"][k - 1])
+        P = sh.gather_cov()
+        sh.sync()
+        P = P.cpu().numpy()
+        X, V, _ = fb.get_state(0)
+        ft = fb.get_features(0)
+        d = g["diagP"][k - 1]
+        errs = [helpers.rel_err(X, g["X"][k - 1]), helpers.rel_err(V, g["V"][k - 1]),
+                helpers.rel_err(ft["pib"], g["pib"][k - 1]), float(np.max(np.abs(np.diag(P) - d) / d)),
+                abs(np.trace(P) - g["traceP"][k - 1]) / g["traceP"][k - 1],
+                abs(np.linalg.norm(P) - g["frobP"][k - 1]) / g["frobP"][k - 1],
+                float(np.max(np.abs(P[si, sj] - g["sampleP"][k - 1]) / np.sqrt(d[si] * d[sj]))),
+                float(np.max(np.abs(P - P.T)) / np.max(d))]
+        assert np.all(np.isfinite(P)) and max(errs) < TOL, (k, errs)
+        worst = max(worst, max(errs))
+    print("2000 features, row-block sharded: worst deviation from the golden values %.2e" % worst)
+    sh.close()
+    fb.close()
+
+
 def test_shard_of_the_65536_filter_batch():
     """configs[4] on one of its eight GPUs: 8192 filters x 32 features, each with its own pixel noise."""
     from oracle import oracle as orc
