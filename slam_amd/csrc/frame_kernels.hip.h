@@ -101,4 +101,33 @@ __global__ void __launch_bounds__(256) frame_remap_cov_kernel(FilterView fv, Fra
     out[e] = v;
 }
 
+// The same surgery in place for covariances that fit LDS (nl <= 128): one workgroup per filter reads its nl x nl block
+// with contiguous 16-byte loads and writes the gathered block over it, one pass over P instead of two.
+// grid (filters), 512 threads, dynamic LDS nl * nl doubles.
+__global__ void __launch_bounds__(512) frame_remap_cov_lds_kernel(FilterView fv, FrameStage st, double* __restrict__ P,
+                                                                   int nl, double p0)
+{
+    extern __shared__ double rimg[];                 // [nl][nl]
+    const int b = blockIdx.x, g = st.grp[b];
+    if (!st.changed[g]) return;                      // the same for the whole workgroup
+    double* Pb = P + (long long)b * fv.ldn * fv.ldn;
+    const int half = nl >> 1;
+    for (int idx = threadIdx.x; idx < nl * half; idx += 512) {
+        const int r = idx / half, c2 = idx - r * half;
+        reinterpret_cast<double2*>(rimg + r * nl)[c2] = reinterpret_cast<const double2*>(Pb + (long long)r * fv.ldn)[c2];
+    }
+    __syncthreads();
+    const int* src = st.imap + (long long)g * fv.ldn;
+    for (int idx = threadIdx.x; idx < nl * half; idx += 512) {
+        const int i = idx / half, c2 = idx - i * half, j = 2 * c2;
+        const int si = src[i], s0 = src[j], s1 = src[j + 1];
+        double v0 = 0.0, v1 = 0.0;
+        if (si >= 0 && s0 >= 0) v0 = rimg[si * nl + s0];
+        else if (i == j && si == -1) v0 = p0;
+        if (si >= 0 && s1 >= 0) v1 = rimg[si * nl + s1];
+        else if (i == j + 1 && si == -1) v1 = p0;
+        reinterpret_cast<double2*>(Pb + (long long)i * fv.ldn)[c2] = make_double2(v0, v1);
+    }
+}
+
 }  // namespace slamk

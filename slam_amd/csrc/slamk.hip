@@ -1298,9 +1298,17 @@ static int apply_frames(slamk_handle* h, int b0, int cnt, const std::vector<Fram
     if (any_changed) hipLaunchKernelGGL(frame_stash_kernel, fgrid, dim3(256), 0, st, rg.fv, fs, tmp);
     hipLaunchKernelGGL(frame_gather_kernel, fgrid, dim3(256), 0, st, rg.fv, fs, tmp, 1 / h->prm.dinit);
     if (any_changed) {
-        const dim3 cgrid((nl + 63) / 64, (nl + 3) / 4, cnt);
-        hipLaunchKernelGGL(frame_remap_cov_kernel<false>, cgrid, dim3(256), 0, st, rg.fv, fs, rg.fv.P, rg.T, nl, h->prm.p0);
-        hipLaunchKernelGGL(frame_remap_cov_kernel<true>, cgrid, dim3(256), 0, st, rg.fv, fs, rg.fv.P, rg.T, nl, h->prm.p0);
+        const size_t img = (size_t)nl * nl * sizeof(double);
+        if (nl <= 128) {         // the covariance of a filter fits LDS: in place, one pass
+            // (the attribute is set once per device: ask for the largest image this path takes)
+            int rc_ = ensure_dynamic_lds(h, reinterpret_cast<const void*>(frame_remap_cov_lds_kernel), 128 * 128 * sizeof(double));
+            if (rc_) return rc_;
+            hipLaunchKernelGGL(frame_remap_cov_lds_kernel, dim3(cnt), dim3(512), img, st, rg.fv, fs, rg.fv.P, nl, h->prm.p0);
+        } else {
+            const dim3 cgrid((nl + 63) / 64, (nl + 3) / 4, cnt);
+            hipLaunchKernelGGL(frame_remap_cov_kernel<false>, cgrid, dim3(256), 0, st, rg.fv, fs, rg.fv.P, rg.T, nl, h->prm.p0);
+            hipLaunchKernelGGL(frame_remap_cov_kernel<true>, cgrid, dim3(256), 0, st, rg.fv, fs, rg.fv.P, rg.T, nl, h->prm.p0);
+        }
     }
     HIPCHK(h, hipGetLastError());
     for (int c = 0; c < cnt; ++c) {
