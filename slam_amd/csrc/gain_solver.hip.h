@@ -33,6 +33,10 @@
 #ifndef SOLVER_STAMP
 #define SOLVER_STAMP(i)
 #endif
+// Reach of the eager part of the forward solve in the pipelined form, in tile columns (timing builds vary it).
+#ifndef SOLVER_EAGER
+#define SOLVER_EAGER 0
+#endif
 
 namespace slamk {
 
@@ -446,8 +450,14 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
     // The first loads of P (columns 0..2 of every row, and the first panel's feature columns, whose start comes
     // straight from global memory) are requested before the compact rows of H are staged: one global round trip
     // instead of three in a row at the start of the workgroup.
-    const int ec = tid & 15, ea = tid >> 4;              // panel column, row within a group of 32 rows
-    double px[4][3], pf[4][3];                           // P[a][0..2] once, P[a][cs..cs+2] per panel
+    // Pipelined form (two panel buffers): the panels are built by wavefronts 1..7 beside the factorisation, one
+    // column ahead of its need, and wavefront 0 only runs the chain of diagonal tiles; see the LAZY branch below.
+    constexpr bool LAZY = TWO_PANELS;
+    constexpr int RS = LAZY ? 28 : 32, UR = LAZY ? 5 : 4;   // rows per pass of the building threads, passes (n <= 128)
+    const int pt = LAZY ? tid - 64 : tid;                // index among the building threads (wavefront 0: none)
+    const bool builder = pt >= 0;
+    const int ec = pt & 15, ea = pt >> 4;                // panel column, row within a group of RS rows
+    double px[UR][3], pf[UR][3];                         // P[a][0..2] once, P[a][cs..cs+2] per panel
     // what the border step needs from memory is requested here, a whole factorisation ahead of its use
     double w_alt = 0.0, sigma_alt = 0.0;
     if constexpr (BORDER) {
@@ -456,12 +466,14 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
     }
     {
         const long long rb = (long long)b * ldm;
-        const int cs0 = max(fv.hcs[rb + ec], 0);
+        if (builder) {
+            const int cs0 = max(fv.hcs[rb + ec], 0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const double* row = Pb + (long long)min(ea + 32 * u, nl - 1) * ldn;
-            px[u][0] = row[0]; px[u][1] = row[1]; px[u][2] = row[2];
-            pf[u][0] = row[cs0]; pf[u][1] = row[cs0 + 1]; pf[u][2] = row[cs0 + 2];
+            for (int u = 0; u < UR; ++u) {
+                const double* row = Pb + (long long)min(ea + RS * u, nl - 1) * ldn;
+                px[u][0] = row[0]; px[u][1] = row[1]; px[u][2] = row[2];
+                pf[u][0] = row[cs0]; pf[u][1] = row[cs0 + 1]; pf[u][2] = row[cs0 + 2];
+            }
         }
         for (int t = tid; t < 3 * M; t += 512) { cha[t] = fv.ha[rb * 3 + t]; chb[t] = fv.hb[rb * 3 + t]; }
         for (int t = tid; t < M; t += 512) { crd[t] = rd[t]; ccs[t] = fv.hcs[rb + t]; }
@@ -474,8 +486,8 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
         auto load_panel = [&](int j) {                   // the entries of P in the observed feature's columns
             const int cs = max(ccs[16 * j + ec], 0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double* row = Pb + (long long)min(ea + 32 * u, nl - 1) * ldn + cs;
+            for (int u = 0; u < UR; ++u) {
+                const double* row = Pb + (long long)min(ea + RS * u, nl - 1) * ldn + cs;
                 pf[u][0] = row[0]; pf[u][1] = row[1]; pf[u][2] = row[2];
             }
         };
@@ -485,8 +497,8 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
             {
                 const int q = 16 * j + ec;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int a = ea + 32 * u;
+                for (int u = 0; u < UR; ++u) {
+                    const int a = ea + RS * u;
                     double v = px[u][0] * cha[3 * q];
                     v = fma(px[u][1], cha[3 * q + 1], v);
                     v = fma(px[u][2], cha[3 * q + 2], v);
@@ -543,12 +555,298 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
     };
 
     // ---- factorisation and Y^T = inv(L) W^T ------------------------------------------------------------------
-    tile_cholesky_forward<MT>(lds, y, has_blk, Lb, ldm, wave, lane, build, [&](int j) {
+    auto late_tile = [&](int j) {
         v4d t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) t[r] = Kpark[(long long)li * ldm + 16 * j + lk + 4 * r];
         return t;
-    });
+    };
+    if constexpr (!LAZY) {
+        tile_cholesky_forward<MT>(lds, y, has_blk, Lb, ldm, wave, lane, build, late_tile);
+    } else {
+        // Pipelined form.  Column c of S is needed for the first time when column c - 1 of L is final, and all it
+        // takes to form it is panel c of W: the build runs beside the factorisation instead of in front of it, and
+        // the updates are applied left-looking with a look-ahead of one column.  During tile column j (after its
+        // panel tiles L_ij are final) wavefronts 1..7
+        //   - apply column j to column j + 1                        S_i,j+1 -= L_ij L_j+1,j^T   (the only update
+        //     that has to wait for column j),
+        //   - form the tiles of column j + 2 from panel j + 2 (written to LDS during column j - 1) and bring them up
+        //     to date with columns 0..j,
+        //   - write panel j + 3 of W into the buffer panel j + 1 has left and request the entries of P for panel j + 4,
+        //   - advance the forward solve,
+        // while wavefront 0 updates, factors and inverts the diagonal tile j + 1: what every tile column costs is the
+        // chain of wavefront 0, and the build phase disappears behind it.  Same sums in the same order per tile as the
+        // right-looking form (columns ascending).
+        auto pan_of = [&](int c) { return pan0 + ((c & 1) ? 8 * 256 : 0); };
+        auto write_panel = [&](int p) {                  // panel p of W from the entries of P held in registers
+            double* pan = pan_of(p);
+            const int q = 16 * p + ec;
+            const double a0 = cha[3 * q], a1 = cha[3 * q + 1], a2 = cha[3 * q + 2];
+            const double b0 = chb[3 * q], b1 = chb[3 * q + 1], b2 = chb[3 * q + 2];
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                const int a = ea + RS * u;
+                double v = px[u][0] * a0;
+                v = fma(px[u][1], a1, v);
+                v = fma(px[u][2], a2, v);
+                v = fma(pf[u][0], b0, v);
+                v = fma(pf[u][1], b1, v);
+                v = fma(pf[u][2], b2, v);
+                if (a < nl) pan[(a >> 4) * 256 + tsw(a & 15, ec)] = v;
+            }
+        };
+        auto load_panel = [&](int p) {                   // the entries of P in the observed feature's columns
+            const int cs = max(ccs[16 * p + ec], 0);
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                const double* row = Pb + (long long)min(ea + RS * u, nl - 1) * ldn + cs;
+                pf[u][0] = row[0]; pf[u][1] = row[1]; pf[u][2] = row[2];
+            }
+        };
+        auto form_tile = [&](int i, int c) {             // S tile (i, c) = H_i W_c + R; lane = row q of S, 4 columns each
+            const double* pan = pan_of(c);
+            double* tl = lds + tile_index(i, c) * 256;
+            const int q = 16 * i + li;
+            const int cs = max(ccs[q], 0);
+            const double a0 = cha[3 * q], a1 = cha[3 * q + 1], a2 = cha[3 * q + 2];
+            const double b0 = chb[3 * q], b1 = chb[3 * q + 1], b2 = chb[3 * q + 2];
+            const double rq = crd[q];
+            double x0[4], x1[4], x2[4], y0[4], y1[4], y2[4], v[4];
+            tile_ld4(pan, 0, 4 * lk, x0);
+            tile_ld4(pan, 1, 4 * lk, x1);
+            tile_ld4(pan, 2, 4 * lk, x2);
+            tile_ld4(pan + (cs >> 4) * 256, cs & 15, 4 * lk, y0);
+            tile_ld4(pan + ((cs + 1) >> 4) * 256, (cs + 1) & 15, 4 * lk, y1);
+            tile_ld4(pan + ((cs + 2) >> 4) * 256, (cs + 2) & 15, 4 * lk, y2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double w = a0 * x0[r];
+                w = fma(a1, x1[r], w);
+                w = fma(a2, x2[r], w);
+                w = fma(b0, y0[r], w);
+                w = fma(b1, y1[r], w);
+                w = fma(b2, y2[r], w);
+                if (q == 16 * c + 4 * lk + r) w += rq;
+                v[r] = w;
+            }
+            tile_st4(tl, li, 4 * lk, v);
+        };
+        auto panel_tile = [&](int i, int j) {            // L_ij = S_ij inv(L_jj)^T
+            double* tij = lds + tile_index(i, j) * 256;
+            v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+            acc = tile_mma_ldsBt<false>(tij, lds + tile_index(j, j) * 256, acc, li, lk);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tij[tsw(lk + 4 * r, li)] = acc[r];
+        };
+        // S_ic -= sum_{k = k0}^{k1} L_ik L_ck^T: two interleaved accumulator chains, k ascending in each; the operands
+        // of the next product are requested before the matrix instructions of the current one are issued
+        auto update_tile = [&](int i, int c, int k0, int k1) {
+            double* tic = lds + tile_index(i, c) * 256;
+            const double* ri = lds + tile_index(i, 0) * 256;
+            const double* rc = lds + tile_index(c, 0) * 256;
+            const int o0 = li * 16 + ((4 * lk) ^ (li & 14)), o1 = li * 16 + ((4 * lk + 2) ^ (li & 14));
+            double2 a01, a23, b01, b23;
+            auto fetch = [&](int k) {
+                a01 = *reinterpret_cast<const double2*>(ri + k * 256 + o0);
+                a23 = *reinterpret_cast<const double2*>(ri + k * 256 + o1);
+                b01 = *reinterpret_cast<const double2*>(rc + k * 256 + o0);
+                b23 = *reinterpret_cast<const double2*>(rc + k * 256 + o1);
+            };
+            fetch(k0);
+            v4d acc, acc2 = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = tic[tsw(lk + 4 * r, li)];
+#pragma unroll
+            for (int k = 0; k < MT; ++k)
+                if (k >= k0 && k <= k1) {
+                    const double x0 = -a01.x, x1 = -a01.y, x2 = -a23.x, x3 = -a23.y;
+                    const double z0 = b01.x, z1 = b01.y, z2 = b23.x, z3 = b23.y;
+                    if (k < k1) fetch(k + 1);
+                    v4d& d = ((k - k0) & 1) ? acc2 : acc;
+                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, z0, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, z1, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, z2, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, z3, d, 0, 0, 0);
+                }
+            acc += acc2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tic[tsw(lk + 4 * r, li)] = acc[r];
+        };
+        // Forward solve of the wavefront's row block, column j:  Y^T_j = inv(L_jj) (W^T_j - sum_{k<j} L_jk Y^T_k).
+        // The terms with j - k <= EAGER were already subtracted from y[j] when Y^T_k became final (independent
+        // accumulators, no dependent chain, and the work per tile column is about the same from the first column to
+        // the last instead of growing with j); the others are summed here.  y[c] starts at zero and takes the tile
+        // of W^T when its panel arrives.
+        constexpr int EAGER = SOLVER_EAGER;
+        auto forward_column = [&](int j) {
+            v4d acc = y[j], acc2 = (v4d){0.0, 0.0, 0.0, 0.0};
+            double an[4];
+            auto fetch = [&](int r, int k) {             // row fragment of L_rk (k < r) or of inv(L_rr) (k == r)
+                const double* ta = lds + tile_index(r, k) * 256;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) an[s] = ta[tsw(li, 4 * s + lk)];
+            };
+            fetch(j, j - EAGER > 0 ? 0 : j);
+#pragma unroll
+            for (int k = 0; k < MT; ++k)
+                if (k < j - EAGER) {
+                    const double a0 = -an[0], a1 = -an[1], a2 = -an[2], a3 = -an[3];
+                    fetch(j, k + 1 < j - EAGER ? k + 1 : j);
+                    v4d& c = (k & 1) ? acc2 : acc;
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, y[k][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, y[k][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, y[k][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, y[k][3], c, 0, 0, 0);
+                }
+            acc += acc2;
+            v4d out = (v4d){0.0, 0.0, 0.0, 0.0};
+            {
+                const double a0 = an[0], a1 = an[1], a2 = an[2], a3 = an[3];
+                if (j + 1 < MT && EAGER > 0) fetch(j + 1, j);
+                out = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, acc[0], out, 0, 0, 0);
+                out = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, acc[1], out, 0, 0, 0);
+                out = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, acc[2], out, 0, 0, 0);
+                out = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, acc[3], out, 0, 0, 0);
+            }
+            y[j] = out;
+#pragma unroll
+            for (int c = 0; c < MT; ++c)
+                if (c > j && c - j <= EAGER) {
+                    const double a0 = -an[0], a1 = -an[1], a2 = -an[2], a3 = -an[3];
+                    if (c + 1 < MT && c + 1 - j <= EAGER) fetch(c + 1, j);
+                    y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, out[0], y[c], 0, 0, 0);
+                    y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, out[1], y[c], 0, 0, 0);
+                    y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, out[2], y[c], 0, 0, 0);
+                    y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, out[3], y[c], 0, 0, 0);
+                }
+        };
+        auto forward_step = [&](int j, v4d acc) {        // as in tile_cholesky_forward
+            v4d acc2 = (v4d){0.0, 0.0, 0.0, 0.0};
+            double an[4];
+            auto fetch = [&](int k) {
+                const double* ta = lds + tile_index(j, k) * 256;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) an[s] = ta[tsw(li, 4 * s + lk)];
+            };
+            fetch(j > 0 ? 0 : j);
+#pragma unroll
+            for (int k = 0; k < MT; ++k)
+                if (k < j) {
+                    const double a0 = -an[0], a1 = -an[1], a2 = -an[2], a3 = -an[3];
+                    fetch(k + 1);
+                    v4d& c = (k & 1) ? acc2 : acc;
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, y[k][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, y[k][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, y[k][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, y[k][3], c, 0, 0, 0);
+                }
+            acc += acc2;
+            v4d out = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) out = __builtin_amdgcn_mfma_f64_16x16x4f64(an[s], acc[s], out, 0, 0, 0);
+            return out;
+        };
+        if (wave == 0) {
+            // tile (blk, c) of W for the eighth row block, parked in this block's rows of K until the factorisation is
+            // done (wavefront 0 writes and reads them itself)
+            auto park = [&](int c) {
+                const double* pan = pan_of(c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Kpark[(long long)li * ldm + 16 * c + lk + 4 * r] = pan[blk * 256 + tsw(li, lk + 4 * r)];
+            };
+            __syncthreads();                             // panel 0 is in LDS
+            if (has_blk) park(0);
+            __syncthreads();                             // column 0 of S and panel 1 are in LDS
+            SOLVER_STAMP(1);
+            if (has_blk && 1 < MT) park(1);
+            {
+                v4d a0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a0[r] = lds[tsw(lk + 4 * r, li)];
+                diag_tile_factor_invert_acc(a0, lds, Lb, ldm, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                __syncthreads();                         // A
+                if (j + 1 < MT) panel_tile(j + 1, j);
+                __syncthreads();                         // B
+                if (has_blk && j + 2 < MT) park(j + 2);
+                if (j + 1 < MT) {                        // the update with column j stays in registers
+                    double* tjj = lds + tile_index(j + 1, j + 1) * 256;
+                    const double* tp = lds + tile_index(j + 1, j) * 256;
+                    v4d acc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = tjj[tsw(lk + 4 * r, li)];
+                    acc = tile_mma_ldsBt<true>(tp, tp, acc, li, lk);
+                    diag_tile_factor_invert_acc(acc, tjj, Lb ? Lb + (long long)(16 * (j + 1)) * ldm + 16 * (j + 1) : nullptr,
+                                                ldm, lane);
+                }
+                SOLVER_STAMP(2 + j);
+            }
+            __syncthreads();
+            if (has_blk) {
+#pragma unroll
+                for (int j = 0; j < MT; ++j) y[j] = forward_step(j, late_tile(j));
+            }
+        } else {
+            // wavefront 4 shares its SIMD with wavefront 0: it takes no panel tiles and no updates of column j + 1,
+            // and a tile of the look-ahead column only when there are more than six
+            const int wk6 = wave < 4 ? wave - 1 : (wave == 4 ? 6 : wave - 2);  // 0..5 for wavefronts 1 2 3 5 6 7, 6 for 4
+            const bool worker = wave != 4;
+            // the tiles of the look-ahead column go to one wavefront per SIMD first (their sums get long on the late
+            // columns, where SIMD 0 has the most room): wavefronts 4 1 2 3 5 6 7
+            const int wq = wave == 4 ? 0 : (wave < 4 ? wave : wave - 1);
+            auto take_y = [&](int c) {                   // tile (blk, c) of W, transposed: accumulator layout of W^T
+                const double* pan = pan_of(c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[c < MT ? c : 0][r] += pan[blk * 256 + tsw(li, lk + 4 * r)];
+            };
+#pragma unroll
+            for (int j = 0; j < MT; ++j) y[j] = (v4d){0.0, 0.0, 0.0, 0.0};
+            write_panel(0);
+            if (1 < MT) load_panel(1);
+            __syncthreads();                             // panel 0 is in LDS
+            for (int i = wk6; i < MT; i += 7) form_tile(i, 0);
+            if (has_blk) take_y(0);
+            if (1 < MT) {
+                write_panel(1);
+                if (2 < MT) load_panel(2);
+            }
+            __syncthreads();                             // column 0 of S and panel 1 are in LDS
+            SOLVER_STAMP(1);
+            if (1 < MT) {
+                for (int i = 1 + wk6; i < MT; i += 7) form_tile(i, 1);
+                if (has_blk) take_y(1);
+            }
+            if (2 < MT) {
+                write_panel(2);
+                if (3 < MT) load_panel(3);
+            }
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                __syncthreads();                         // A
+                if (worker)
+                    for (int i = j + 2 + wk6; i < MT; i += 6) panel_tile(i, j);
+                __syncthreads();                         // B
+                if (worker)
+                    for (int i = j + 2 + wk6; i < MT; i += 6) update_tile(i, j + 1, j, j);
+                if (j + 3 < MT) {
+                    write_panel(j + 3);
+                    if (j + 4 < MT) load_panel(j + 4);
+                }
+                if (j + 2 < MT) {
+                    for (int i = j + 2 + wq; i < MT; i += 7) {
+                        form_tile(i, j + 2);
+                        update_tile(i, j + 2, 0, j);
+                    }
+                    if (has_blk) take_y(j + 2);
+                }
+                if (has_blk) forward_column(j);
+                SOLVER_STAMP(2 + j);
+            }
+            __syncthreads();
+        }
+    }
     if (Lb) store_offdiag_tiles<MT>(lds, Lb, ldm, wave, lane);
     SOLVER_STAMP(20);
 
