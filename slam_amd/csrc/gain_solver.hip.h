@@ -33,10 +33,6 @@
 #ifndef SOLVER_STAMP
 #define SOLVER_STAMP(i)
 #endif
-// Reach of the eager part of the forward solve in the pipelined form, in tile columns (timing builds vary it).
-#ifndef SOLVER_EAGER
-#define SOLVER_EAGER 0
-#endif
 
 namespace slamk {
 
@@ -672,54 +668,6 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
 #pragma unroll
             for (int r = 0; r < 4; ++r) tic[tsw(lk + 4 * r, li)] = acc[r];
         };
-        // Forward solve of the wavefront's row block, column j:  Y^T_j = inv(L_jj) (W^T_j - sum_{k<j} L_jk Y^T_k).
-        // The terms with j - k <= EAGER were already subtracted from y[j] when Y^T_k became final (independent
-        // accumulators, no dependent chain, and the work per tile column is about the same from the first column to
-        // the last instead of growing with j); the others are summed here.  y[c] starts at zero and takes the tile
-        // of W^T when its panel arrives.
-        constexpr int EAGER = SOLVER_EAGER;
-        auto forward_column = [&](int j) {
-            v4d acc = y[j], acc2 = (v4d){0.0, 0.0, 0.0, 0.0};
-            double an[4];
-            auto fetch = [&](int r, int k) {             // row fragment of L_rk (k < r) or of inv(L_rr) (k == r)
-                const double* ta = lds + tile_index(r, k) * 256;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) an[s] = ta[tsw(li, 4 * s + lk)];
-            };
-            fetch(j, j - EAGER > 0 ? 0 : j);
-#pragma unroll
-            for (int k = 0; k < MT; ++k)
-                if (k < j - EAGER) {
-                    const double a0 = -an[0], a1 = -an[1], a2 = -an[2], a3 = -an[3];
-                    fetch(j, k + 1 < j - EAGER ? k + 1 : j);
-                    v4d& c = (k & 1) ? acc2 : acc;
-                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, y[k][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, y[k][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, y[k][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, y[k][3], c, 0, 0, 0);
-                }
-            acc += acc2;
-            v4d out = (v4d){0.0, 0.0, 0.0, 0.0};
-            {
-                const double a0 = an[0], a1 = an[1], a2 = an[2], a3 = an[3];
-                if (j + 1 < MT && EAGER > 0) fetch(j + 1, j);
-                out = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, acc[0], out, 0, 0, 0);
-                out = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, acc[1], out, 0, 0, 0);
-                out = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, acc[2], out, 0, 0, 0);
-                out = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, acc[3], out, 0, 0, 0);
-            }
-            y[j] = out;
-#pragma unroll
-            for (int c = 0; c < MT; ++c)
-                if (c > j && c - j <= EAGER) {
-                    const double a0 = -an[0], a1 = -an[1], a2 = -an[2], a3 = -an[3];
-                    if (c + 1 < MT && c + 1 - j <= EAGER) fetch(c + 1, j);
-                    y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, out[0], y[c], 0, 0, 0);
-                    y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, out[1], y[c], 0, 0, 0);
-                    y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, out[2], y[c], 0, 0, 0);
-                    y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, out[3], y[c], 0, 0, 0);
-                }
-        };
         auto forward_step = [&](int j, v4d acc) {        // as in tile_cholesky_forward
             v4d acc2 = (v4d){0.0, 0.0, 0.0, 0.0};
             double an[4];
@@ -795,14 +743,12 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
             const bool worker = wave != 4;
             // the tiles of the look-ahead column go to one wavefront per SIMD first (their sums get long on the late
             // columns, where SIMD 0 has the most room): wavefronts 4 1 2 3 5 6 7
-            const int wq = wave == 4 ? 0 : (wave < 4 ? wave : wave - 1);
+            const int wq = wave == 4 ? 6 : 5 - wk6;
             auto take_y = [&](int c) {                   // tile (blk, c) of W, transposed: accumulator layout of W^T
                 const double* pan = pan_of(c);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) y[c < MT ? c : 0][r] += pan[blk * 256 + tsw(li, lk + 4 * r)];
+                for (int r = 0; r < 4; ++r) y[c < MT ? c : 0][r] = pan[blk * 256 + tsw(li, lk + 4 * r)];
             };
-#pragma unroll
-            for (int j = 0; j < MT; ++j) y[j] = (v4d){0.0, 0.0, 0.0, 0.0};
             write_panel(0);
             if (1 < MT) load_panel(1);
             __syncthreads();                             // panel 0 is in LDS
@@ -841,7 +787,7 @@ __global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double*
                     }
                     if (has_blk) take_y(j + 2);
                 }
-                if (has_blk) forward_column(j);
+                if (has_blk) y[j] = forward_step(j, y[j]);
                 SOLVER_STAMP(2 + j);
             }
             __syncthreads();
