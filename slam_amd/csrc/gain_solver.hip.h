@@ -412,8 +412,10 @@ struct SolverLds {
 // (src/slam/main.cpp:354), so s = -(row 2 of W_f)^T, hence l = -(row 2 of Y_f)^T: the forward solve has already
 // produced it; w_a = -P[:, 2], sigma = P[2][2] + r_a.  Filters of the batch whose altitude row lies inside the tiles
 // (m - 1 < 16 MT) take the plain path.
+// Launches of up to three tiles per side (filters of up to about ten features) are chains of latency with little LDS: their
+// registers are capped at 128 so that two workgroups share a CU (measured at 4 features, 4096 filters: 0.127 -> 0.089 ms).
 template <int MT, bool BORDER>
-__global__ void __launch_bounds__(512) gain_solver_kernel(FilterView fv, double* __restrict__ K, double* __restrict__ KR,
+__global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(FilterView fv, double* __restrict__ K, double* __restrict__ KR,
                                                            double* __restrict__ L, long long sM, long long sNM, int NT)
 {
     extern __shared__ double lds[];                     // SolverLds<MT>::TILES tiles of 256 doubles

@@ -417,8 +417,9 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
 //   order of phases: chunks (K R K^T into o; A, dx) -> A fragments to registers, P tiles to LDS -> A P ->
 //   (A P) A^T added into o -> store.
 // LDS: NT^2 tiles (A, then P / AP) + 2 NT tiles (chunks of K) + 10 tiles (diag R, dx, altitude column, compact rows of H).
+// (NT <= 2: registers capped at 128 so that two workgroups share a CU; at NT = 3 the spills cost more than that gains)
 template <int NT>
-__global__ void __launch_bounds__(512) joseph_merged_kernel(FilterView fv, const double* __restrict__ K, int ldk,
+__global__ void __launch_bounds__(512, (NT <= 2 ? 4 : 2)) joseph_merged_kernel(FilterView fv, const double* __restrict__ K, int ldk,
                                                              long long sK, int mlc, int form, double* __restrict__ dx,
                                                              int apply, int* __restrict__ applied)
 {
