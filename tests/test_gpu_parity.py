@@ -586,6 +586,34 @@ def test_full_size_batch_properties():
         assert np.linalg.eigvalsh(P).min() > 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nf,ref_fraction", [(4, 0.5), (8, 0.5), (20, 0.5), (24, 0.0), (28, 1.0), (32, 0.5), (38, 0.0)])
+def test_identical_filters_give_identical_results(nf, ref_fraction):
+    """1024 filters with the same inputs: the per-filter kernels run the same instructions on the same data in every
+    workgroup, so every covariance and state must equal those of filter 0 bit for bit, whatever CU a workgroup lands on
+    and however its wavefronts interleave; a missing barrier or a read ahead of its producer shows up here.  Filter 0
+    is held to the oracle."""
+    B = 1024
+    st = synth.gen_stream(seed=5, nf=nf, steps=4, churn=False, image_every=1, ref_fraction=ref_fraction)
+    inp = helpers.stream_inputs(st, 77)
+    so = helpers.run_oracle(st, inp=inp)[0]
+    fb = ekf.FilterBatch(max_features=nf, batch=B)
+    for b in range(B):
+        fb.set_state(b, X=st.init_pos)
+    fb.frame(-1, inp[0][5], inp[0][1])
+    for k in range(1, 4):
+        u, quat, ang, acc, dt, matches = inp[k]
+        fb.frame(-1, matches, quat)
+        fb.predict(np.tile(quat, B), np.tile(ang, B), np.tile(acc, B), np.full(B, dt))
+        fb.update(np.tile(quat, B))
+        P0, x0 = fb.get_cov(0), fb.state_vector(0)
+        assert helpers.rel_err(P0, so[k - 1]["P"]) < TOL
+        for b in range(1, B, 3):
+            assert np.array_equal(fb.get_cov(b), P0), (k, b)
+            assert np.array_equal(fb.state_vector(b), x0), (k, b)
+    fb.close()
+
+
 def _run_sharded(rank, world, group, nf, steps, dev, rccl_single_rank=False, blocks=None):
     """The stream of the sharded tests through slamk_sharded_* on this rank; returns (P, state vector).
     blocks: (outer panel columns, rows of the inverse blocks) for this run."""
