@@ -151,6 +151,18 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmArgs g)
     const double* aBase = &As[(wr * (BM / 2) + li) * LDS_K + 2 * lk];
     const double* bBase = TB ? &Bs[(wc * (BN / 2) + li) * LDS_K + 2 * lk] : &Bs[2 * lk * LDS_N + wc * (BN / 2) + li];
 
+    // Small tile: a wavefront skips the 16 x 16 blocks of its sub-tile that lie outside C or (LOWER) strictly above the
+    // diagonal -- batched matrices of 130..300 rows are a few tiles with wide rims, and the rim blocks would otherwise
+    // cost as much as the live ones.  The conditions are uniform over the wavefront.
+    constexpr bool SKIP = BM < 128;
+    bool live[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int r0 = m0 + wr * (BM / 2) + i * 16, c0 = n0 + wc * (BN / 2) + j * 16;
+            live[i][j] = !SKIP || (r0 < g.M && c0 < g.N && !(LOWER && c0 > r0 + 15));
+        }
     auto compute = [&](int buf) {
         const double* aB = aBase + buf * A_SZ;
         const double* bB = bBase + buf * B_SZ;
@@ -168,12 +180,12 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmArgs g)
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[i].x, b2[j].x, acc[i][j], 0, 0, 0);
+                    if (live[i][j]) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[i].x, b2[j].x, acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[i].y, b2[j].y, acc[i][j], 0, 0, 0);
+                    if (live[i][j]) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[i].y, b2[j].y, acc[i][j], 0, 0, 0);
         }
     };
 
@@ -211,6 +223,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmArgs g)
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
+            if (!live[i][j]) continue;                 // outside C, or above the diagonal like a skipped tile: not stored
             const int col = n0 + wc * (BN / 2) + j * 16 + li;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -967,6 +967,12 @@ double gemm_flops(int M, int N, int K, bool lower, int tri)
             if (tri == TRI_B_KLE_N) ke = std::min(K, n0 + BN);
             if (tri == TRI_B_KGE_N) kb = std::min(K, n0);
             if (tri == TRI_A_KLE_M) ke = std::min(K, m0 + BM);
+            if (lower && !big) {        // the small tile also skips its 16 x 16 blocks strictly above the diagonal
+                for (int r0 = m0; r0 < std::min(M, m0 + BM); r0 += 16)
+                    for (int c0 = n0; c0 < std::min(N, n0 + BN); c0 += 16)
+                        if (c0 <= r0 + 15) f += 2.0 * std::min(16, M - r0) * std::min(16, N - c0) * std::max(0, ke - kb);
+                continue;
+            }
             f += 2.0 * std::min(BM, M - m0) * std::min(BN, N - n0) * std::max(0, ke - kb);
         }
     return f;
