@@ -878,8 +878,9 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
 // Diagonal block of the blocked Cholesky of a large S: factor the 16 MT x 16 MT block at (j0, j0) (lower part
 // valid) into L and write inv(L) of the block into Li, one workgroup per matrix of the batch.  The inverse is
 // the forward solve above with the identity as right-hand side.
+// (registers capped at 128: two workgroups share a CU when a batch of mid-size filters factors its blocks together)
 template <int MT>
-__global__ void __launch_bounds__(512) chol_inv_block_kernel(const double* __restrict__ S, double* __restrict__ L,
+__global__ void __launch_bounds__(512, 4) chol_inv_block_kernel(const double* __restrict__ S, double* __restrict__ L,
                                                               double* __restrict__ Li, int ld, long long sM, int j0,
                                                               int* __restrict__ status)
 {
