@@ -163,9 +163,10 @@ def test_altimeter_input_without_the_override():
     assert updates >= 5
 
 
-def test_random_configurations_against_oracle():
-    """Seeded sweep over feature counts, reflection fractions, churn patterns and both covariance forms."""
-    rng = np.random.default_rng(2024)
+@pytest.mark.parametrize("seed", [2024, 7, 99])
+def test_random_configurations_against_oracle(seed):
+    """Seeded sweep over feature counts, reflection fractions, churn patterns and the three update forms."""
+    rng = np.random.default_rng(seed)
     worst = 0.0
     for case in range(14):
         nf = int(rng.integers(1, 44))
@@ -177,7 +178,7 @@ def test_random_configurations_against_oracle():
             kw.update(drop_at=int(rng.integers(3, steps - 3)), drop_count=int(rng.integers(1, min(nf, 5))))
         if rng.integers(0, 2):
             kw.update(add_at=int(rng.integers(3, steps - 2)), add_count=int(rng.integers(1, 6)))
-        st = synth.gen_stream(seed=500 + case, nf=nf, steps=steps, churn=churn, ref_fraction=ref, **kw)
+        st = synth.gen_stream(seed=seed + 500 + case, nf=nf, steps=steps, churn=churn, ref_fraction=ref, **kw)
         so, _ = helpers.run_oracle(st)
         p = ekf.default_params()
         p.update_form = int(rng.integers(0, 3))
