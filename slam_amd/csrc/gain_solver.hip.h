@@ -190,7 +190,7 @@ __device__ __forceinline__ double pick4(const double* v, int k)
 //     R -= L[:, 4 kb ..] X_kb, again one MFMA.
 // The two chains (factor, inverse) only share X and interleave.  A pivot that is not positive turns into NaN.
 __device__ __forceinline__ void diag_tile_factor_invert_acc(v4d a, double* __restrict__ t, double* __restrict__ Lg,
-                                                            int ldl, int lane)
+                                                            int ldl, int lane, double* __restrict__ t2 = nullptr)
 {
     const int li = lane & 15, lk = lane >> 4;
     v4d R, out;
@@ -227,6 +227,10 @@ __device__ __forceinline__ void diag_tile_factor_invert_acc(v4d a, double* __res
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) t[tsw(lk + 4 * r, li)] = out[r];
+    if (t2) {                                            // second image of inv(L) (see SPILL in gain_solver_kernel)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t2[tsw(lk + 4 * r, li)] = out[r];
+    }
 }
 
 // Tile Cholesky of the MT x MT lower tiles in LDS (tile (i, j) at tile_index(i, j)) together with the forward
@@ -393,15 +397,20 @@ __device__ __forceinline__ void store_offdiag_tiles(const double* lds, double* L
 
 // LDS beyond the S tiles: scratch tile of the diagonal-tile routine + eight per-wavefront staging tiles during
 // and after the factorisation; before it, the compact rows of H and one 16-column panel of W = P H^T.
-template <int MT>
+// SPILL (MT > 10: S does not fit): the pipelined form with only SPILL_CAP tiles of S / L in LDS, see the kernel.
+template <int MT, bool SPILL = false>
 struct SolverLds {
     static constexpr int M = 16 * MT;
     static constexpr int COEF_TILES = (15 * M / 2 + 255) / 256;          // ha, hb [M][3], r [M], cs [M] (int)
     // two panels of W (one barrier per panel instead of two) where 160 KB allow it
-    static constexpr bool TWO_PANELS = MT * (MT + 1) / 2 + COEF_TILES + 16 <= 80;
-    static constexpr int EXTRA_TILES = COEF_TILES + (TWO_PANELS ? 16 : 8);
-    static constexpr int TILES = MT * (MT + 1) / 2 + EXTRA_TILES;
+    // (SPILL also keeps columns 0..2 of P behind the panels: 2 tiles)
+    static constexpr bool TWO_PANELS = SPILL || MT * (MT + 1) / 2 + COEF_TILES + 16 <= 80;
+    static constexpr int EXTRA_TILES = COEF_TILES + (TWO_PANELS ? 16 : 8) + (SPILL ? 2 : 0);
+    static constexpr int SPILL_CAP = 79 - EXTRA_TILES;                   // tiles of S / L resident at a time
+    static constexpr int TILES = (SPILL ? SPILL_CAP : MT * (MT + 1) / 2) + EXTRA_TILES;
 };
+// first tile (in column order) of column c of the lower triangle
+__host__ __device__ constexpr int solver_col_off(int MT, int c) { return (c < MT ? c : MT) * MT - (c < MT ? c : MT) * ((c < MT ? c : MT) - 1) / 2; }
 
 // BORDER: the launch covers 16 MT rows of S as tiles and one more row, the altitude row, which the library keeps
 // LAST (row m - 1).  For a filter with m - 1 == 16 MT that row is factored as a border of the tiled block,
@@ -414,11 +423,20 @@ struct SolverLds {
 // (m - 1 < 16 MT) take the plain path.
 // Launches of up to three tiles per side (filters of up to about ten features) are chains of latency with little LDS: their
 // registers are capped at 128 so that two workgroups share a CU (measured at 4 features, 4096 filters: 0.127 -> 0.089 ms).
-template <int MT, bool BORDER>
+// SPILL (launches of more than 10 tiles per side, whose S does not fit LDS): the pipelined form only needs the three
+// tile columns in flight on chip.  The tiles of S / L take their places in LDS in the order they are formed (column by
+// column) in a ring of SPILL_CAP tiles; every tile is also written to an image of the factor in global memory (Lsp, sSp
+// doubles per filter, tile c_off(k) + i - k at 256 doubles each, same layout inside a tile) when it becomes final, and a
+// finished tile whose place has since gone to a later column is read from there (it sits in L2).  Which it is follows
+// from the tile's position in column order and the column being formed -- no flags.  At 12 tile columns 21 of the 78
+// tiles end up outside LDS; during the factorisation only a few operand reads go there, in the backward solve a quarter.
+template <int MT, bool BORDER, bool SPILL = false>
 __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(FilterView fv, double* __restrict__ K, double* __restrict__ KR,
-                                                           double* __restrict__ L, long long sM, long long sNM, int NT)
+                                                           double* __restrict__ L, long long sM, long long sNM, int NT,
+                                                           double* __restrict__ Lsp = nullptr, long long sSp = 0)
 {
-    extern __shared__ double lds[];                     // SolverLds<MT>::TILES tiles of 256 doubles
+    extern __shared__ double lds[];                     // SolverLds<MT, SPILL>::TILES tiles of 256 doubles
+    using Lds = SolverLds<MT, SPILL>;
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -431,8 +449,28 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
     const int blk = (wave + 7) & 7;
     const bool has_blk = blk < NT;
     const int nl = 16 * NT;
-    double* scratch = lds + NTILES * 256;
+    constexpr int CAP = SPILL ? Lds::SPILL_CAP : NTILES;   // tiles of S / L in LDS
+    double* scratch = lds + CAP * 256;
     double* stg = scratch + (1 + wave) * 256;           // per-wavefront staging tile (after the build phase)
+    double* Lsb = SPILL ? Lsp + (long long)blockIdx.x * sSp : nullptr;
+    // tile (i, k), i >= k, of S / L: its place in LDS (valid from the moment it is formed until the ring comes round)
+    auto tslot = [&](int i, int k) -> double* {
+        if constexpr (SPILL) return lds + ((k * MT - k * (k - 1) / 2 + (i - k)) % CAP) * 256;
+        else return lds + tile_index(i, k) * 256;
+    };
+    // ... and where to read it from once it is final, while the tiles before `thr` (in column order) have left LDS
+    auto tread = [&](int i, int k, int thr) -> const double* {
+        if constexpr (SPILL) {
+            const int t = k * MT - k * (k - 1) / 2 + (i - k);
+            return t >= thr ? lds + (t % CAP) * 256 : Lsb + (long long)t * 256;
+        } else
+            return lds + tile_index(i, k) * 256;
+    };
+    // the tile's place in the global image (SPILL only)
+    auto timage = [&](int i, int k) -> double* { return Lsb + (long long)(k * MT - k * (k - 1) / 2 + (i - k)) * 256; };
+    // tiles that have left LDS while column c is the newest one formed / after the factorisation
+    auto thr_at = [&](int c) { const int f = solver_col_off(MT, c + 1) - CAP; return f > 0 ? f : 0; };
+    constexpr int THR_END = (SPILL && NTILES > CAP) ? NTILES - CAP : 0;
     const double* rd = fv.rdiag + (long long)b * ldm;
     const double* Pb = fv.P + (long long)b * ldn * ldn;
 
@@ -443,8 +481,8 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
     double* chb = cha + 3 * M;                           // [M][3]
     double* crd = chb + 3 * M;                           // [M]
     int* ccs = reinterpret_cast<int*>(crd + M);          // [M]
-    double* pan0 = scratch + SolverLds<MT>::COEF_TILES * 256;  // NT tiles: rows of W, 16 columns (x 2 where LDS allows)
-    constexpr bool TWO_PANELS = SolverLds<MT>::TWO_PANELS;
+    double* pan0 = scratch + Lds::COEF_TILES * 256;  // NT tiles: rows of W, 16 columns (x 2 where LDS allows)
+    constexpr bool TWO_PANELS = Lds::TWO_PANELS;
     // The first loads of P (columns 0..2 of every row, and the first panel's feature columns, whose start comes
     // straight from global memory) are requested before the compact rows of H are staged: one global round trip
     // instead of three in a row at the start of the workgroup.
@@ -455,7 +493,11 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
     const int pt = LAZY ? tid - 64 : tid;                // index among the building threads (wavefront 0: none)
     const bool builder = pt >= 0;
     const int ec = pt & 15, ea = pt >> 4;                // panel column, row within a group of RS rows
-    double px[UR][3], pf[UR][3];                         // P[a][0..2] once, P[a][cs..cs+2] per panel
+    // P[a][0..2] once (in registers; in LDS with SPILL, whose registers are needed for the longer rows of tiles of the
+    // solves: 1.5 % slower per panel, measured at 10 tile columns), P[a][cs..cs+2] per panel
+    constexpr bool PXLDS = SPILL;
+    double px[PXLDS ? 1 : UR][3], pf[UR][3];
+    double* pxs = pan0 + 16 * 256;                       // [nl][3] (PXLDS)
     // what the border step needs from memory is requested here, a whole factorisation ahead of its use
     double w_alt = 0.0, sigma_alt = 0.0;
     if constexpr (BORDER) {
@@ -469,9 +511,12 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
 #pragma unroll
             for (int u = 0; u < UR; ++u) {
                 const double* row = Pb + (long long)min(ea + RS * u, nl - 1) * ldn;
-                px[u][0] = row[0]; px[u][1] = row[1]; px[u][2] = row[2];
+                if constexpr (!PXLDS) { px[u][0] = row[0]; px[u][1] = row[1]; px[u][2] = row[2]; }
                 pf[u][0] = row[cs0]; pf[u][1] = row[cs0 + 1]; pf[u][2] = row[cs0 + 2];
             }
+        }
+        if constexpr (PXLDS) {
+            for (int t = tid; t < 3 * nl; t += 512) pxs[t] = Pb[(long long)(t / 3) * ldn + (t % 3)];
         }
         for (int t = tid; t < 3 * M; t += 512) { cha[t] = fv.ha[rb * 3 + t]; chb[t] = fv.hb[rb * 3 + t]; }
         for (int t = tid; t < M; t += 512) { crd[t] = rd[t]; ccs[t] = fv.hcs[rb + t]; }
@@ -584,9 +629,16 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
 #pragma unroll
             for (int u = 0; u < UR; ++u) {
                 const int a = ea + RS * u;
-                double v = px[u][0] * a0;
-                v = fma(px[u][1], a1, v);
-                v = fma(px[u][2], a2, v);
+                double x0, x1, x2;
+                if constexpr (PXLDS) {
+                    const double* xr = pxs + 3 * min(a, nl - 1);
+                    x0 = xr[0]; x1 = xr[1]; x2 = xr[2];
+                } else {
+                    x0 = px[u][0]; x1 = px[u][1]; x2 = px[u][2];
+                }
+                double v = x0 * a0;
+                v = fma(x1, a1, v);
+                v = fma(x2, a2, v);
                 v = fma(pf[u][0], b0, v);
                 v = fma(pf[u][1], b1, v);
                 v = fma(pf[u][2], b2, v);
@@ -603,7 +655,7 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
         };
         auto form_tile = [&](int i, int c) {             // S tile (i, c) = H_i W_c + R; lane = row q of S, 4 columns each
             const double* pan = pan_of(c);
-            double* tl = lds + tile_index(i, c) * 256;
+            double* tl = tslot(i, c);
             const int q = 16 * i + li;
             const int cs = max(ccs[q], 0);
             const double a0 = cha[3 * q], a1 = cha[3 * q + 1], a2 = cha[3 * q + 2];
@@ -630,25 +682,30 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
             tile_st4(tl, li, 4 * lk, v);
         };
         auto panel_tile = [&](int i, int j) {            // L_ij = S_ij inv(L_jj)^T
-            double* tij = lds + tile_index(i, j) * 256;
+            double* tij = tslot(i, j);
             v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-            acc = tile_mma_ldsBt<false>(tij, lds + tile_index(j, j) * 256, acc, li, lk);
+            acc = tile_mma_ldsBt<false>(tij, tslot(j, j), acc, li, lk);
 #pragma unroll
             for (int r = 0; r < 4; ++r) tij[tsw(lk + 4 * r, li)] = acc[r];
+            if constexpr (SPILL) {                       // final: second image in global memory
+                double* tg = timage(i, j);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tg[tsw(lk + 4 * r, li)] = acc[r];
+            }
         };
         // S_ic -= sum_{k = k0}^{k1} L_ik L_ck^T: two interleaved accumulator chains, k ascending in each; the operands
         // of the next product are requested before the matrix instructions of the current one are issued
-        auto update_tile = [&](int i, int c, int k0, int k1) {
-            double* tic = lds + tile_index(i, c) * 256;
-            const double* ri = lds + tile_index(i, 0) * 256;
-            const double* rc = lds + tile_index(c, 0) * 256;
+        auto update_tile = [&](int i, int c, int k0, int k1, int thr) {
+            double* tic = tslot(i, c);
             const int o0 = li * 16 + ((4 * lk) ^ (li & 14)), o1 = li * 16 + ((4 * lk + 2) ^ (li & 14));
             double2 a01, a23, b01, b23;
             auto fetch = [&](int k) {
-                a01 = *reinterpret_cast<const double2*>(ri + k * 256 + o0);
-                a23 = *reinterpret_cast<const double2*>(ri + k * 256 + o1);
-                b01 = *reinterpret_cast<const double2*>(rc + k * 256 + o0);
-                b23 = *reinterpret_cast<const double2*>(rc + k * 256 + o1);
+                const double* ri = tread(i, k, thr);
+                const double* rc = tread(c, k, thr);
+                a01 = *reinterpret_cast<const double2*>(ri + o0);
+                a23 = *reinterpret_cast<const double2*>(ri + o1);
+                b01 = *reinterpret_cast<const double2*>(rc + o0);
+                b23 = *reinterpret_cast<const double2*>(rc + o1);
             };
             fetch(k0);
             v4d acc, acc2 = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -670,11 +727,11 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
 #pragma unroll
             for (int r = 0; r < 4; ++r) tic[tsw(lk + 4 * r, li)] = acc[r];
         };
-        auto forward_step = [&](int j, v4d acc) {        // as in tile_cholesky_forward
+        auto forward_step = [&](int j, v4d acc, int thr) {   // as in tile_cholesky_forward
             v4d acc2 = (v4d){0.0, 0.0, 0.0, 0.0};
             double an[4];
             auto fetch = [&](int k) {
-                const double* ta = lds + tile_index(j, k) * 256;
+                const double* ta = tread(j, k, thr);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) an[s] = ta[tsw(li, 4 * s + lk)];
             };
@@ -713,7 +770,7 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
                 v4d a0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a0[r] = lds[tsw(lk + 4 * r, li)];
-                diag_tile_factor_invert_acc(a0, lds, Lb, ldm, lane);
+                diag_tile_factor_invert_acc(a0, lds, Lb, ldm, lane, SPILL ? timage(0, 0) : nullptr);
             }
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
@@ -722,21 +779,21 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
                 __syncthreads();                         // B
                 if (has_blk && j + 2 < MT) park(j + 2);
                 if (j + 1 < MT) {                        // the update with column j stays in registers
-                    double* tjj = lds + tile_index(j + 1, j + 1) * 256;
-                    const double* tp = lds + tile_index(j + 1, j) * 256;
+                    double* tjj = tslot(j + 1, j + 1);
+                    const double* tp = tslot(j + 1, j);
                     v4d acc;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[r] = tjj[tsw(lk + 4 * r, li)];
                     acc = tile_mma_ldsBt<true>(tp, tp, acc, li, lk);
                     diag_tile_factor_invert_acc(acc, tjj, Lb ? Lb + (long long)(16 * (j + 1)) * ldm + 16 * (j + 1) : nullptr,
-                                                ldm, lane);
+                                                ldm, lane, SPILL ? timage(j + 1, j + 1) : nullptr);
                 }
                 SOLVER_STAMP(2 + j);
             }
             __syncthreads();
             if (has_blk) {
 #pragma unroll
-                for (int j = 0; j < MT; ++j) y[j] = forward_step(j, late_tile(j));
+                for (int j = 0; j < MT; ++j) y[j] = forward_step(j, late_tile(j), THR_END);
             }
         } else {
             // wavefront 4 shares its SIMD with wavefront 0: it takes no panel tiles and no updates of column j + 1,
@@ -777,7 +834,7 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
                     for (int i = j + 2 + wk6; i < MT; i += 6) panel_tile(i, j);
                 __syncthreads();                         // B
                 if (worker)
-                    for (int i = j + 2 + wk6; i < MT; i += 6) update_tile(i, j + 1, j, j);
+                    for (int i = j + 2 + wk6; i < MT; i += 6) update_tile(i, j + 1, j, j, 0);
                 if (j + 3 < MT) {
                     write_panel(j + 3);
                     if (j + 4 < MT) load_panel(j + 4);
@@ -785,17 +842,30 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
                 if (j + 2 < MT) {
                     for (int i = j + 2 + wq; i < MT; i += 7) {
                         form_tile(i, j + 2);
-                        update_tile(i, j + 2, 0, j);
+                        update_tile(i, j + 2, 0, j, thr_at(j + 2));
                     }
                     if (has_blk) take_y(j + 2);
                 }
-                if (has_blk) y[j] = forward_step(j, y[j]);
+                if (has_blk) y[j] = forward_step(j, y[j], thr_at(j + 2));
                 SOLVER_STAMP(2 + j);
             }
             __syncthreads();
         }
     }
-    if (Lb) store_offdiag_tiles<MT>(lds, Lb, ldm, wave, lane);
+    if constexpr (SPILL) {
+        if (Lb)                                          // off-diagonal tiles of L for introspection
+            for (int t = wave; t < NTILES; t += 8) {
+                int i = 0;
+                while ((i + 1) * (i + 2) / 2 <= t) ++i;
+                const int j = t - i * (i + 1) / 2;
+                if (i == j) continue;
+                const double* tl = tread(i, j, THR_END);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Lb[(long long)(16 * i + lk + 4 * r) * ldm + 16 * j + li] = tl[tsw(lk + 4 * r, li)];
+            }
+    } else {
+        if (Lb) store_offdiag_tiles<MT>(lds, Lb, ldm, wave, lane);
+    }
     SOLVER_STAMP(20);
 
     // ---- the altitude row as a border of the factored block -----------------------------------------------
@@ -856,11 +926,11 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
         v4d acc = y[j], acc2 = (v4d){0.0, 0.0, 0.0, 0.0};      // two interleaved chains, as in the forward solve
 #pragma unroll
         for (int k = j + 1; k < MT; k += 2) {
-            acc = tile_mma_regB<true, true>(lds + tile_index(k, j) * 256, y[k], acc, li, lk);
-            if (k + 1 < MT) acc2 = tile_mma_regB<true, true>(lds + tile_index(k + 1, j) * 256, y[k + 1], acc2, li, lk);
+            acc = tile_mma_regB<true, true>(tread(k, j, THR_END), y[k], acc, li, lk);
+            if (k + 1 < MT) acc2 = tile_mma_regB<true, true>(tread(k + 1, j, THR_END), y[k + 1], acc2, li, lk);
         }
         acc += acc2;
-        y[j] = tile_mma_regB<true, false>(lds + tile_index(j, j) * 256, acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
+        y[j] = tile_mma_regB<true, false>(tread(j, j, THR_END), acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
 #pragma unroll
         for (int r = 0; r < 4; ++r) stg[tsw(li, lk + 4 * r)] = y[j][r];
 #pragma unroll

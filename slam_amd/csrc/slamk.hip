@@ -63,6 +63,7 @@ struct slamk_handle {
     double *Hm = nullptr;                                                        // [B][ldm][ldn]
     double *W = nullptr, *Y = nullptr, *K = nullptr, *KR = nullptr;              // [B][ldn][ldm]
     double *S = nullptr, *L = nullptr, *Li = nullptr;                            // [B][ldm][ldm]
+    double *Lsp = nullptr;                  // [B][SOLVER_SPILL_IMAGE]: tile image of the factor for the gain solver's spill form
     double *dx = nullptr;                                                        // [B][ldn]
     // staging
     double *qbw_d = nullptr, *w_d = nullptr, *acc_d = nullptr, *dt_d = nullptr, *alt_d = nullptr;
@@ -258,7 +259,10 @@ int max_m(const slamk_handle* h)
     return m;
 }
 
-constexpr int SOLVER_MAX_MT = 11, SOLVER_MAX_NT = 8;
+constexpr int SOLVER_MAX_MT = 13, SOLVER_MAX_NT = 8;
+// more than SOLVER_LDS_MT tile columns: S does not fit LDS and the solver keeps an image of the factor in global memory
+constexpr int SOLVER_LDS_MT = 10;
+constexpr size_t SOLVER_SPILL_IMAGE = (size_t)SOLVER_MAX_MT * (SOLVER_MAX_MT + 1) / 2 * 256;   // doubles per filter
 
 // The altitude row is the last measurement row.  When the feature rows of the largest filter fill their 16-row
 // tiles exactly (m - 1 a multiple of 16), the per-filter kernels cover only those tiles and take the altitude row
@@ -277,7 +281,8 @@ bool use_seq_update(const slamk_handle* h, int nl) { return h->prm.update_form =
 
 // Workspaces beyond P, T and K.  The per-filter fused kernels keep every intermediate in LDS, so a batch of small
 // filters never touches these: they are allocated when a layout or the debug switch first needs them.
-enum { WS_GAIN = 1,     // W, Y, KR, S, L, Li: gain by blocked Cholesky + GEMMs
+enum { WS_SPILL = 8,    // Lsp
+       WS_GAIN = 1,     // W, Y, KR, S, L, Li: gain by blocked Cholesky + GEMMs
        WS_COV = 2,      // Am, AP: covariance update by GEMMs
        WS_DENSE = 4 };  // Fm, Hm (and L): dense Jacobians and the factor for slamk_debug_get*
 
@@ -287,6 +292,7 @@ int ensure_workspaces(slamk_handle* h)
     int need = 0;
     const bool seq = use_seq_update(h, nl);    // the block-sequential update keeps everything in LDS
     if (!seq && !use_fused_solver(nl, mm)) need |= WS_GAIN;
+    if (!seq && use_fused_solver(nl, mm) && tiled_rows(mm) > 16 * SOLVER_LDS_MT) need |= WS_SPILL;
     if (!seq && !use_fused_joseph(nl, mm)) need |= WS_COV;
     if (h->debug) need |= WS_DENSE;
     need &= ~h->have_ws;
@@ -299,6 +305,7 @@ int ensure_workspaces(slamk_handle* h)
         rc |= dalloc(h, &h->S, B * ldm * ldm); rc |= dalloc(h, &h->Li, B * ldm * ldm);
     }
     if (need & WS_COV) { rc |= dalloc(h, &h->Am, B * ldn * ldn); rc |= dalloc(h, &h->AP, B * ldn * ldn); }
+    if (need & WS_SPILL) rc |= dalloc(h, &h->Lsp, B * SOLVER_SPILL_IMAGE);
     if (need & WS_DENSE) { rc |= dalloc(h, &h->Fm, B * ldn * ldn); rc |= dalloc(h, &h->Hm, B * ldm * ldn); }
     if (rc) return SLAMK_EHIP;
     HIPCHK(h, hipDeviceSynchronize());          // the zero fill is complete before any stream uses the buffers
@@ -381,7 +388,7 @@ void launch_left(const RowSparse& M, const double* In, int ldi, long long sIn, d
 struct Range {
     FilterView fv;
     int B;
-    double *T, *W, *K, *KR, *Y, *S, *L, *Li, *Am, *AP, *Hm, *Fm, *dx;
+    double *T, *W, *K, *KR, *Y, *S, *L, *Li, *Lsp, *Am, *AP, *Hm, *Fm, *dx;
 };
 
 Range make_range(const slamk_handle* h, int b0, int cnt)
@@ -405,6 +412,7 @@ Range make_range(const slamk_handle* h, int b0, int cnt)
     r.Fm = at(h->Fm, ldn * ldn * o); r.Hm = at(h->Hm, ldm * ldn * o);
     r.W = at(h->W, ldn * ldm * o); r.K = h->K + ldn * ldm * o; r.KR = at(h->KR, ldn * ldm * o); r.Y = at(h->Y, ldn * ldm * o);
     r.S = at(h->S, ldm * ldm * o); r.L = at(h->L, ldm * ldm * o); r.Li = at(h->Li, ldm * ldm * o);
+    r.Lsp = at(h->Lsp, SOLVER_SPILL_IMAGE * o);
     r.dx = h->dx + ldn * o;
     return r;
 }
@@ -637,11 +645,13 @@ int run_cholesky_inverse(slamk_handle* h, const Range& rg, int ml, hipStream_t s
 template <int MT, bool BORDER>
 int launch_gain_solver(slamk_handle* h, const Range& rg, int nl, double* Lout, hipStream_t st)
 {
-    const size_t lds = (size_t)SolverLds<MT>::TILES * 256 * sizeof(double);
-    { int rc_ = ensure_dynamic_lds(h, reinterpret_cast<const void*>(gain_solver_kernel<MT, BORDER>), lds); if (rc_) return rc_; }
+    constexpr bool SPILL = MT > SOLVER_LDS_MT;
+    const size_t lds = (size_t)SolverLds<MT, SPILL>::TILES * 256 * sizeof(double);
+    { int rc_ = ensure_dynamic_lds(h, reinterpret_cast<const void*>(gain_solver_kernel<MT, BORDER, SPILL>), lds); if (rc_) return rc_; }
+    if (SPILL && !rg.Lsp) return fail(h, SLAMK_EINVAL, "gain solver: no image buffer for %d measurement tiles", MT);
     const long long sM = (long long)h->ldm * h->ldm, sNM = (long long)h->ldn * h->ldm;
-    hipLaunchKernelGGL((gain_solver_kernel<MT, BORDER>), dim3(rg.B), dim3(512), lds, st, rg.fv, rg.K, (double*)nullptr, Lout,
-                       sM, sNM, nl / 16);
+    hipLaunchKernelGGL((gain_solver_kernel<MT, BORDER, SPILL>), dim3(rg.B), dim3(512), lds, st, rg.fv, rg.K, (double*)nullptr,
+                       Lout, sM, sNM, nl / 16, rg.Lsp, (long long)SOLVER_SPILL_IMAGE);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -661,6 +671,8 @@ int run_gain_solver_b(slamk_handle* h, const Range& rg, int nl, int mt, double* 
         case 9: return launch_gain_solver<9, BORDER>(h, rg, nl, Lout, st);
         case 10: return launch_gain_solver<10, BORDER>(h, rg, nl, Lout, st);
         case 11: return launch_gain_solver<11, BORDER>(h, rg, nl, Lout, st);
+        case 12: return launch_gain_solver<12, BORDER>(h, rg, nl, Lout, st);
+        case 13: return launch_gain_solver<13, BORDER>(h, rg, nl, Lout, st);
         default: return fail(h, SLAMK_EINVAL, "gain solver: %d measurement tiles out of range", mt);
     }
 }
