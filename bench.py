@@ -31,10 +31,10 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X: 256 CU x 2.4 GHz x 128 fp64 FLOP/clk/
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E
 
 
-def build_inputs(torch, dev, B, nf, nsteps, rank):
+def build_inputs(torch, dev, B, nf, nsteps, rank, ref_fraction=0.5):
     """Truth stream shared by all filters, independent pixel noise per filter and step."""
     from slam_amd import synth
-    st = synth.gen_stream(seed=1, nf=nf, steps=nsteps + 1, churn=False, image_every=1, ref_fraction=0.5)
+    st = synth.gen_stream(seed=1, nf=nf, steps=nsteps + 1, churn=False, image_every=1, ref_fraction=ref_fraction)
     g = torch.Generator(device=dev)
     g.manual_seed(1000 + rank)
     steps = []

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Stage times (HIP events inside the library) of one workload point: python scripts/stage_times.py NF BATCH [STEPS]"""
+"""Stage times (HIP events inside the library) of one workload point: python scripts/stage_times.py NF BATCH [STEPS [REF_FRACTION]]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +11,8 @@ from slam_amd import ekf
 nf, B = int(sys.argv[1]), int(sys.argv[2])
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 dev = torch.device("cuda", 0)
-st, steps = bench.build_inputs(torch, dev, B, nf, iters + 2, 0)
+ref = float(sys.argv[4]) if len(sys.argv) > 4 else 0.5
+st, steps = bench.build_inputs(torch, dev, B, nf, iters + 2, 0, ref)
 fb = ekf.FilterBatch(max_features=nf, batch=B)
 for b in range(B):
     fb.set_state(b, X=st.init_pos)

@@ -259,7 +259,7 @@ int max_m(const slamk_handle* h)
     return m;
 }
 
-constexpr int SOLVER_MAX_MT = 13, SOLVER_MAX_NT = 8;
+constexpr int SOLVER_MAX_MT = 15, SOLVER_MAX_NT = 8;
 // more than SOLVER_LDS_MT tile columns: S does not fit LDS and the solver keeps an image of the factor in global memory
 constexpr int SOLVER_LDS_MT = 10;
 constexpr size_t SOLVER_SPILL_IMAGE = (size_t)SOLVER_MAX_MT * (SOLVER_MAX_MT + 1) / 2 * 256;   // doubles per filter
@@ -673,6 +673,8 @@ int run_gain_solver_b(slamk_handle* h, const Range& rg, int nl, int mt, double* 
         case 11: return launch_gain_solver<11, BORDER>(h, rg, nl, Lout, st);
         case 12: return launch_gain_solver<12, BORDER>(h, rg, nl, Lout, st);
         case 13: return launch_gain_solver<13, BORDER>(h, rg, nl, Lout, st);
+        case 14: return launch_gain_solver<14, BORDER>(h, rg, nl, Lout, st);
+        case 15: return launch_gain_solver<15, BORDER>(h, rg, nl, Lout, st);
         default: return fail(h, SLAMK_EINVAL, "gain solver: %d measurement tiles out of range", mt);
     }
 }

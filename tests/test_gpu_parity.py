@@ -87,12 +87,14 @@ def test_single_filter_stream_parity(nf, form):
 
 
 @pytest.mark.parametrize("nf,ref_fraction,form", [(2, 0.5, 0), (38, 0.0, 0), (38, 0.0, 1), (26, 1.0, 0), (36, 1.0, 0),
-                                                  (13, 0.5, 0), (29, 0.5, 0), (1, 1.0, 0),
+                                                  (13, 0.5, 0), (29, 0.5, 0), (1, 1.0, 0), (34, 0.5, 0), (36, 0.5, 0),
+                                                  (39, 0.5, 0), (39, 1.0, 0), (39, 1.0, 1), (32, 1.0, 0),
                                                   (2, 0.5, 2), (38, 0.0, 2), (36, 1.0, 2), (13, 0.5, 2), (1, 1.0, 2),
                                                   (50, 0.5, 2), (45, 1.0, 2)])
 def test_fused_path_tile_count_edges(nf, ref_fraction, form):
     """Smallest filter, eight 16-row blocks of the state (n = 123), all-reflection rows (m = 157), and a filter
-    whose S exceeds the fused solver (m = 217) while its P still fits the fused covariance update (n = 117); state
+    whose S exceeds LDS (m = 171 .. 235: the solver keeps the finished tiles of the factor in an image in global
+    memory, 11 to 15 tile columns) while its P still fits the fused covariance update (n <= 126); state
     dimensions that fill their tiles exactly (n = 48, 96: no padding rows); a single reflective feature.  Form 2 (the
     block-sequential update) at the same edges and at its own: n = 159 (ten row blocks, its limit) and m = 271."""
     st = synth.gen_stream(seed=70 + nf, nf=nf, steps=31, churn=False, ref_fraction=ref_fraction)
@@ -588,7 +590,8 @@ def test_full_size_batch_properties():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nf,ref_fraction", [(4, 0.5), (8, 0.5), (20, 0.5), (24, 0.0), (28, 1.0), (32, 0.5), (38, 0.0)])
+@pytest.mark.parametrize("nf,ref_fraction", [(4, 0.5), (8, 0.5), (20, 0.5), (24, 0.0), (28, 1.0), (32, 0.5), (38, 0.0),
+                                             (36, 0.5), (36, 1.0), (39, 1.0)])
 def test_identical_filters_give_identical_results(nf, ref_fraction):
     """1024 filters with the same inputs: the per-filter kernels run the same instructions on the same data in every
     workgroup, so every covariance and state must equal those of filter 0 bit for bit, whatever CU a workgroup lands on
