@@ -2,13 +2,16 @@
 //
 //   in : P  n x n, the compact rows of H, r[m] (diagonal of R); W = P H^T and S = H W + R are formed in LDS
 //   out: K  n x m, optionally KR = K diag(r) and L (lower)
-//   m = 16 MT with MT <= 11 (the lower tiles of S, 2 KB each, live in LDS: MT (MT+1) / 2 <= 66 tiles),
+//   m = 16 MT with MT <= 10 when the lower tiles of S, 2 KB each, all live in LDS (MT (MT+1) / 2 <= 55 tiles), MT <= 15
+//   with the finished tiles of the factor partly in an image in global memory (SPILL),
 //   n = 16 NT with NT <= 8 (one wavefront per 16 columns of W^T).
 //
-// Tile Cholesky, right-looking, in LDS.  Per tile column j: wavefront 0 factors the diagonal tile and
-//   replaces it by its inverse; the tiles below become S_ij inv(L_jj)^T; the trailing tiles take
-//   S_ik -= L_ij L_kj^T, column j + 1 first so that wavefront 0 can factor the next diagonal tile while the
-//   other wavefronts finish the trailing update and advance the forward solve.  All tile products are
+// Tile Cholesky in LDS.  Per tile column j: wavefront 0 factors the diagonal tile and replaces it by its inverse;
+//   the tiles below become S_ij inv(L_jj)^T.  gain_solver_kernel applies the updates S_ik -= L_ij L_kj^T
+//   left-looking with one column of look-ahead and forms the columns of S beside the factorisation (its "Pipelined
+//   form"); tile_cholesky_forward, which chol_inv_block_kernel uses on a block that is already in memory, applies them
+//   right-looking, column j + 1 first, so that wavefront 0 can factor the next diagonal tile while the other
+//   wavefronts finish the trailing update and advance the forward solve.  All tile products are
 //   v_mfma_f64_16x16x4_f64.
 // Two triangular solves on the transposed system, so that finished tiles are consumed straight from the
 //   accumulator registers: an MFMA result tile (lane = column, register = row group) IS the B operand of
@@ -481,16 +484,16 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
     double* chb = cha + 3 * M;                           // [M][3]
     double* crd = chb + 3 * M;                           // [M]
     int* ccs = reinterpret_cast<int*>(crd + M);          // [M]
-    double* pan0 = scratch + Lds::COEF_TILES * 256;  // NT tiles: rows of W, 16 columns (x 2 where LDS allows)
+    double* pan0 = scratch + Lds::COEF_TILES * 256;  // two panels of W: 8 tiles (128 rows x 16 columns) each
     constexpr bool TWO_PANELS = Lds::TWO_PANELS;
     // The first loads of P (columns 0..2 of every row, and the first panel's feature columns, whose start comes
     // straight from global memory) are requested before the compact rows of H are staged: one global round trip
     // instead of three in a row at the start of the workgroup.
-    // Pipelined form (two panel buffers): the panels are built by wavefronts 1..7 beside the factorisation, one
-    // column ahead of its need, and wavefront 0 only runs the chain of diagonal tiles; see the LAZY branch below.
-    constexpr bool LAZY = TWO_PANELS;
-    constexpr int RS = LAZY ? 28 : 32, UR = LAZY ? 5 : 4;   // rows per pass of the building threads, passes (n <= 128)
-    const int pt = LAZY ? tid - 64 : tid;                // index among the building threads (wavefront 0: none)
+    // The panels are built by wavefronts 1..7 beside the factorisation, one column ahead of its need (two panel
+    // buffers), and wavefront 0 only runs the chain of diagonal tiles; see "Pipelined form" below.
+    static_assert(TWO_PANELS, "S and two panels of W do not fit LDS: launch with SPILL");
+    constexpr int RS = 28, UR = 5;                       // rows per pass of the building threads, passes (n <= 128)
+    const int pt = tid - 64;                             // index among the building threads (wavefront 0: none)
     const bool builder = pt >= 0;
     const int ec = pt & 15, ea = pt >> 4;                // panel column, row within a group of RS rows
     // P[a][0..2] once (in registers; in LDS with SPILL, whose registers are needed for the longer rows of tiles of the
@@ -525,78 +528,6 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
     SOLVER_STAMP(0);
     v4d y[MT];
     double* Kpark = K + (long long)b * sNM + (long long)(16 * blk) * ldm;
-    auto build = [&](auto with_y) {
-        auto load_panel = [&](int j) {                   // the entries of P in the observed feature's columns
-            const int cs = max(ccs[16 * j + ec], 0);
-#pragma unroll
-            for (int u = 0; u < UR; ++u) {
-                const double* row = Pb + (long long)min(ea + RS * u, nl - 1) * ldn + cs;
-                pf[u][0] = row[0]; pf[u][1] = row[1]; pf[u][2] = row[2];
-            }
-        };
-#pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            double* pan = pan0 + ((TWO_PANELS && (j & 1)) ? 8 * 256 : 0);
-            {
-                const int q = 16 * j + ec;
-#pragma unroll
-                for (int u = 0; u < UR; ++u) {
-                    const int a = ea + RS * u;
-                    double v = px[u][0] * cha[3 * q];
-                    v = fma(px[u][1], cha[3 * q + 1], v);
-                    v = fma(px[u][2], cha[3 * q + 2], v);
-                    v = fma(pf[u][0], chb[3 * q], v);
-                    v = fma(pf[u][1], chb[3 * q + 1], v);
-                    v = fma(pf[u][2], chb[3 * q + 2], v);
-                    if (a < nl) pan[(a >> 4) * 256 + tsw(a & 15, ec)] = v;
-                }
-            }
-            if (j + 1 < MT) load_panel(j + 1);           // in flight while this panel is consumed
-            __syncthreads();
-            for (int i = j + wave; i < MT; i += 8) {     // S tiles (i, j), i >= j; lane = row q of S, 4 columns each
-                double* tl = lds + tile_index(i, j) * 256;
-                const int q = 16 * i + li;
-                const int cs = max(ccs[q], 0);
-                const double a0 = cha[3 * q], a1 = cha[3 * q + 1], a2 = cha[3 * q + 2];
-                const double b0 = chb[3 * q], b1 = chb[3 * q + 1], b2 = chb[3 * q + 2];
-                const double rq = crd[q];
-                // columns 4 lk .. 4 lk + 3: neighbours in the tile image, two 16-byte accesses per row
-                double x0[4], x1[4], x2[4], y0[4], y1[4], y2[4], v[4];
-                tile_ld4(pan, 0, 4 * lk, x0);
-                tile_ld4(pan, 1, 4 * lk, x1);
-                tile_ld4(pan, 2, 4 * lk, x2);
-                tile_ld4(pan + (cs >> 4) * 256, cs & 15, 4 * lk, y0);
-                tile_ld4(pan + ((cs + 1) >> 4) * 256, (cs + 1) & 15, 4 * lk, y1);
-                tile_ld4(pan + ((cs + 2) >> 4) * 256, (cs + 2) & 15, 4 * lk, y2);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int c = 4 * lk + r;
-                    double w = a0 * x0[r];
-                    w = fma(a1, x1[r], w);
-                    w = fma(a2, x2[r], w);
-                    w = fma(b0, y0[r], w);
-                    w = fma(b1, y1[r], w);
-                    w = fma(b2, y2[r], w);
-                    if (q == 16 * j + c) w += rq;
-                    v[r] = w;
-                }
-                tile_st4(tl, li, 4 * lk, v);
-            }
-            if (has_blk) {                               // tile (blk, j) of W, transposed: accumulator layout of W^T
-                if constexpr (decltype(with_y)::value) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) y[j][r] = pan[blk * 256 + tsw(li, lk + 4 * r)];
-                } else {                                 // parked in this block's rows of K until the factorisation is done
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Kpark[(long long)li * ldm + 16 * j + lk + 4 * r] = pan[blk * 256 + tsw(li, lk + 4 * r)];
-                }
-            }
-            // (with two panels the next one is written while stragglers still read this one; the barrier after the
-            // next panel's stores comes before anything overwrites it)
-            if (!TWO_PANELS || j + 1 == MT) __syncthreads();
-        }
-    };
-
     // ---- factorisation and Y^T = inv(L) W^T ------------------------------------------------------------------
     auto late_tile = [&](int j) {
         v4d t;
@@ -604,9 +535,7 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
         for (int r = 0; r < 4; ++r) t[r] = Kpark[(long long)li * ldm + 16 * j + lk + 4 * r];
         return t;
     };
-    if constexpr (!LAZY) {
-        tile_cholesky_forward<MT>(lds, y, has_blk, Lb, ldm, wave, lane, build, late_tile);
-    } else {
+    {
         // Pipelined form.  Column c of S is needed for the first time when column c - 1 of L is final, and all it
         // takes to form it is panel c of W: the build runs beside the factorisation instead of in front of it, and
         // the updates are applied left-looking with a look-ahead of one column.  During tile column j (after its
