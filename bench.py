@@ -280,6 +280,67 @@ def large_map(torch, dev, nf=2000, iters=2):
             "stages_ms": {k: round(v[0] / iters, 3) for k, v in prof.items()}, "cov_sane": ok}
 
 
+def large_map_sharded(torch, dev, dist, rank, world, nf=2000, iters=2):
+    """configs[3] over all ranks: ONE filter with `nf` features, its covariance sharded by row blocks behind the C
+    boundary (slamk_sharded_*), the all-gathers issued by the library on RCCL (or, on a process group without device
+    collectives, through its host-staged callback).  Every rank feeds the same frames (the O(nf) state is replicated).
+    Time = MAX over ranks of `iters` iterations (predict + update) between barriers."""
+    from slam_amd import ekf
+    from slam_amd.sharded import ShardedFilter
+    st, steps = build_inputs(torch, dev, 1, nf, iters + 1, 0)      # the same stream and noise on every rank
+    fb = ekf.FilterBatch(max_features=nf, batch=1, device=dev.index or 0)
+    fb.set_state(0, X=st.init_pos)
+    fb.frame(0, first_frame(st), st.steps[0].quat)
+    n, m = 9 + 3 * nf, fb.num_rows(0)
+    s0 = torch.cuda.Stream(device=dev)
+    sh = ShardedFilter(fb, rank, world, None, device=dev, stream=s0)
+    P0 = torch.from_numpy(fb.get_cov(0)).to(dev)
+    torch.cuda.synchronize(dev)
+    sh.load_cov(P0)
+    dims = sh.dims()
+    cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+
+    def run(k):
+        s = steps[k]
+        fb.frame_begin_dev(s0.cuda_stream)
+        sh.predict(s["qbw"], s["w"], s["acc"], s["dt"])
+        return sh.update(s["qbw"], s["src"], s["refl"])
+    run(0)
+    sh.sync()
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(1, 1 + iters):
+        applied = run(k)
+    sh.sync()
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], device=cdev, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    t = float(tt.item()) / iters
+    P = sh.gather_cov()
+    sh.sync()
+    P = P.cpu().numpy()
+    ok = bool(np.all(np.isfinite(P)) and np.array_equal(P, P.T) and np.all(np.diag(P) > 0) and int(applied.item()) == 1)
+    # every rank must hold the same gathered covariance
+    chk = torch.tensor([float(np.trace(P)), float(np.linalg.norm(P))], device=cdev, dtype=torch.float64)
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    ok = ok and bool(torch.equal(lo, hi))
+    N, M, g = dims["n_padded"], dims["m_padded"], world
+    ob = 512
+    panels = sum(g * (((M - J0 + g - 1) // g + 15) // 16 * 16) * min(ob, M - J0) for J0 in range(0, M, ob))
+    gathered = 8.0 * (13 * g * N + 2 * N * M + panels + N * N)          # rows of T, W, panels of S, K, P
+    sh.close()
+    fb.close()
+    return {"workload": "single filter, %d features (n=%d, m=%d), covariance sharded by row blocks over %d GPUs "
+                        "(slamk_sharded_predict_dev + slamk_sharded_update_dev, %s all-gathers)"
+                        % (nf, n, m, world, "RCCL" if dist.get_backend() == "nccl" else "host-staged (rehearsal)"),
+            "ms_per_update": t * 1e3, "updates_per_s": 1.0 / t, "iters": iters,
+            "rows_per_rank": dims["rows_per_rank"], "bytes_gathered_per_update": gathered,
+            "bytes_received_per_rank_per_update": gathered * (g - 1) / g, "cov_sane": ok}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -290,6 +351,9 @@ def main():
     ap.add_argument("--groups", type=int, default=1, help="ranges of the batch pipelined on streams of their own")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the single-filter and large-map side measurements")
+    ap.add_argument("--sharded-nf", type=int, default=-1,
+                    help="features of the row-block sharded large-map leg of a multi-GPU run (default: 2000 = BASELINE "
+                         "configs[3]; 0 or --no-extra without this flag: skip)")
     args = ap.parse_args()
 
     import torch
@@ -400,6 +464,19 @@ def main():
     # on the device, queued on the same stream without synchronisation (slamk_frame_batch_async).
     churn = churn_workload(torch, dev, B, nf, min(K, 10), rank) if (rank == 0 and not args.no_extra) else None
 
+    # BASELINE configs[3] over the ranks of this run: the one large-map filter, row blocks of its covariance per GPU,
+    # RCCL all-gathers inside the library (every rank takes part; rank 0 reports)
+    sharded_nf = args.sharded_nf if args.sharded_nf >= 0 else (0 if args.no_extra else 2000)
+    sharded = None
+    if dist is not None and sharded_nf > 0:
+        for s_ in steps:
+            s_.clear()                   # the batched workload's inputs are no longer needed: free their HBM
+        torch.cuda.empty_cache()
+        sharded = large_map_sharded(torch, dev, dist, rank, world, nf=sharded_nf)
+        if rank == 0 and not args.no_extra:
+            sharded["one_gpu_unsharded_ms_per_update"] = large_map(torch, dev, nf=sharded_nf)["ms_per_update"]
+        dist.barrier()
+
     if rank == 0:
         # Dominant kernel: gain_solver_kernel (W = P H^T, S = H W + R, tile Cholesky, K = W S^-1), one launch per step, timed
         # with HIP events on the launch stream.  Its algorithmic work is the 16^3 tile products it executes.
@@ -482,6 +559,8 @@ def main():
         }
         if churn is not None:
             out["churn_workload"] = churn
+        if sharded is not None:
+            out.setdefault("also", {})["large_map_sharded"] = sharded
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(st, steps, nf, W, W + K)
         fb.close()

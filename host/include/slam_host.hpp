@@ -21,6 +21,12 @@ struct Vec3d {
     Vec3d(double a, double b, double c) { v[0] = a; v[1] = b; v[2] = c; }
     double& operator[](int i) { return v[i]; }
     const double& operator[](int i) const { return v[i]; }
+    Vec3d& operator+=(const Vec3d& o) { for (int i = 0; i < 3; ++i) v[i] += o.v[i]; return *this; }
+    Vec3d& operator-=(const Vec3d& o) { for (int i = 0; i < 3; ++i) v[i] -= o.v[i]; return *this; }
+    Vec3d& operator*=(double a) { for (int i = 0; i < 3; ++i) v[i] *= a; return *this; }
+    Vec3d operator+(const Vec3d& o) const { return Vec3d(v[0] + o.v[0], v[1] + o.v[1], v[2] + o.v[2]); }
+    Vec3d operator-(const Vec3d& o) const { return Vec3d(v[0] - o.v[0], v[1] - o.v[1], v[2] - o.v[2]); }
+    Vec3d operator*(double a) const { return Vec3d(v[0] * a, v[1] * a, v[2] * a); }
 };
 struct Vec4d {
     double v[4] = {0, 0, 0, 0};
@@ -54,6 +60,17 @@ struct Matx33d {
             for (int k = 0; k < 3; ++k) s += m[3 * i + k] * a[k];
             r[i] = s;
         }
+        return r;
+    }
+    Matx33d operator*(const Matx33d& o) const
+    {
+        Matx33d r;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = 0;
+                for (int k = 0; k < 3; ++k) s += m[3 * i + k] * o.m[3 * k + j];
+                r(i, j) = s;
+            }
         return r;
     }
 };
@@ -201,13 +218,45 @@ struct inits {
 typedef struct inits Inits;
 typedef struct frame Frame;
 
-// include/feature.h:30-222 -- read-only mirror of one tracked feature (States::features is refreshed from the
-// device by States::pull_features): same member and accessor names; the prediction methods (xibHat ... ppbHat,
-// src/ARC/feature.cpp:143-198) run inside the measurement kernel and have no host copy.
+// include/feature.h:30-222 -- mirror of one tracked feature (States::features is refreshed from the device by
+// States::pull_features): same member and accessor names.  The prediction methods (src/ARC/feature.cpp:110-198) are
+// what measure_kernel evaluates on the device; the host copies below exist for callers written against the reference's
+// class and as an independent check of the device innovation (host/typecheck.cpp).
 class Feature {
    public:
     Feature() {}
+    Feature(const Vec3d& pos, int n) : ID(n) { position.body = pos; }              // feature.h: Feature(pos, ID)
     inits initial;
+    // body-frame point (x forward) of the inverse-depth coordinates (y/x, z/x, 1/x)          feature.cpp:171-177
+    Vec3d xibHat() const { return Vec3d(1 / position.body[2], position.body[0] / position.body[2], position.body[1] / position.body[2]); }
+    // world offset from the anchor, seen from the initial body frame                          feature.cpp:110-114
+    Vec3d fromAnchor(const Vec3d& pos) const { return initial.quaternion.rotation().t() * (pos - initial.anchor); }
+    // rotation from the current body frame to the initial one                                 feature.cpp:117-126
+    Matx33d rb2b(const Quaternion& qbw) const { return initial.quaternion.rotation().t() * qbw.rotation(); }
+    Vec3d xib0Hat(const Vec3d& pos, const Quaternion& qbw) const                    // feature.cpp:178-188
+    {
+        Vec3d rv = rb2b(qbw) * xibHat();
+        rv += fromAnchor(pos);
+        return rv;
+    }
+    Vec3d pib0Hat(const Vec3d& pos, const Quaternion& qbw) const                    // feature.cpp:189-198
+    {
+        const Vec3d x = xib0Hat(pos, qbw);
+        return Vec3d(x[1] / x[0], x[2] / x[0], 0);
+    }
+    // the feature's mirror image in the water plane z = 0 (n = e_z: S = I - 2 n n^T)         feature.cpp:155-169
+    Vec3d xpbHat(const Vec3d& X, const Quaternion& qbw) const
+    {
+        Vec3d t = qbw.rotation() * xibHat();
+        t[2] = -t[2];                        // S * (...)
+        t[2] -= 2 * X[2];                    // - 2 n n^T X
+        return qbw.rotation().t() * t;
+    }
+    Vec3d ppbHat(const Vec3d& X, const Quaternion& qbw) const                       // feature.cpp:143-153
+    {
+        const Vec3d x = xpbHat(X, qbw);
+        return Vec3d(x[1] / x[0], x[2] / x[0], 0);
+    }
     int getID() const { return ID; }
     Vec3d get_body_position() const { return position.body; }                      // feature.h:101-105
     Vec3d get_initial_anchor() const { return initial.anchor; }                    // :150-154
@@ -281,15 +330,76 @@ inline void subtract(const View& lhs, const View& rhs, View& dst)
 
 // include/states.h:21-59 -- the state lives on the GPU; this object is the handle plus the host-visible
 // members of the reference's class (X, V, b, features, rf, nrf).  Errors print the reference's message and exit(1).
+// A States without a handle is the plain value the reference passes around (the increment of `dynamics`, the correction
+// `States(kx)`): X, V, b and the body positions of `features`, with the reference's arithmetic on them.
 class States {
    public:
+    States() {}
     explicit States(int max_features)
     {
         slamk_params p;
         slamk_default_params(&p);
         if (slamk_create(&p, max_features, 1, 0, &h) != SLAMK_OK) die("slamk_create");
     }
+    // the correction K e as a state (src/ARC/states.cpp:24-37): rows 0..2 X, 3..5 V, 6 + 3 i .. the body position of
+    // feature i (ID 0); the last three rows (the bias block) are ignored, b stays zero
+    explicit States(const std::vector<double>& kx) : X(kx[0], kx[1], kx[2]), V(kx[3], kx[4], kx[5])
+    {
+        const int nf = ((int)kx.size() - 9) / 3;
+        for (int i = 0; i < nf; ++i) addFeature(Feature(Vec3d(kx[6 + 3 * i], kx[7 + 3 * i], kx[8 + 3 * i]), 0));
+    }
+    States(const States& o) : X(o.X), V(o.V), b(o.b), features(o.features), rf(o.rf), nrf(o.nrf) {}   // a value copy owns no handle
+    States& operator=(const States& o)
+    {
+        X = o.X; V = o.V; b = o.b; features = o.features; rf = o.rf; nrf = o.nrf;
+        return *this;
+    }
     ~States() { if (h) slamk_destroy(h); }
+    States& setX(const Vec3d& pos) { X = pos; return *this; }
+    States& setV(const Vec3d& vel) { V = vel; return *this; }
+    States& setb(const Vec3d& bias) { b = bias; return *this; }
+    States& addFeature(const Feature& f) { features.push_back(f); return *this; }
+    // states.cpp:69-86
+    void add(const States& a)
+    {
+        if (a.features.size() != features.size()) { fprintf(stderr, "add: feature mismatch\n"); exit(EXIT_FAILURE); }
+        X += a.X;
+        V += a.V;
+        for (size_t i = 0; i < features.size(); ++i)
+            features[i].set_body_position(features[i].get_body_position() + a.features[i].get_body_position());
+        b += a.b;
+    }
+    States& operator+=(const States& rhs) { add(rhs); return *this; }               // states.cpp:17-22
+    States& operator*=(const double& rhs)                                           // states.cpp:6-14 (b is not scaled)
+    {
+        X *= rhs;
+        V *= rhs;
+        for (Fiter fi = features.begin(); fi != features.end(); ++fi) fi->set_body_position(fi->get_body_position() * rhs);
+        return *this;
+    }
+    // f(mu) dt of the motion model on the host mirror (states.cpp:222-263; dynamics_kernel is the device form): the
+    // increment that `mu += mu.dynamics(sense, dt)` adds.  Gravity and the -w x V term are commented out in the reference.
+    States dynamics(const Sensors& s, double dt) const
+    {
+        States f;
+        const Matx33d Rb2w = s.quat.get_value().rotation();
+        const Vec3d w = s.ang.get_value();
+        f.X = Rb2w * V;
+        f.V = s.acc.get_value();
+        for (cFiter it = features.begin(); it != features.end(); ++it) {
+            const Vec3d bp = it->get_body_position();
+            Feature fi;
+            fi.set_body_position(Vec3d(
+                (-V[1] + bp[0] * V[0]) * bp[2] + bp[1] * w[0] - (1 + bp[0] * bp[0]) * w[2] + bp[0] * bp[1] * w[1],
+                (-V[2] + bp[1] * V[0]) * bp[2] - bp[0] * w[0] + (1 + bp[1] * bp[1]) * w[1] - bp[0] * bp[1] * w[2],
+                (-w[2] * bp[0] + w[1] * bp[1]) * bp[2] + V[0] * bp[2] * bp[2]));
+            f.addFeature(fi);
+        }
+        f.V -= b;
+        f.b = Vec3d(0, 0, 0);
+        f *= dt;
+        return f;
+    }
     Vec3d X, V, b;
     active features;                 // mirror of the device containers, refreshed by pull_features()
     int rf = 0, nrf = 0;             // features initialised with / without a reflection (states.cpp:203-211)
@@ -320,7 +430,7 @@ class States {
             if (f.initial.isRef) ++rf; else ++nrf;
         }
     }
-    int getNumFeatures() const { return slamk_num_features(h, 0); }
+    int getNumFeatures() const { return h ? slamk_num_features(h, 0) : (int)features.size(); }
     int getRows() const { return 9 + 3 * getNumFeatures(); }
     void pushX() { if (slamk_set_state(h, 0, X.v, nullptr, nullptr)) die("set_state"); }
     void pushV() { if (slamk_set_state(h, 0, nullptr, V.v, nullptr)) die("set_state"); }
@@ -363,5 +473,9 @@ class States {
         exit(EXIT_FAILURE);
     }
 };
+
+// include/states.h:60-70
+inline States operator*(States lhs, const double& rhs) { lhs *= rhs; return lhs; }
+inline States operator+(States lhs, const States& rhs) { lhs += rhs; return lhs; }
 
 }  // namespace slamhost

@@ -24,8 +24,10 @@
  *     on each before a host-pointer entry point.
  *   - Devices.  Handle entry points make the handle's device current for the call and restore the caller's
  *     current device before they return.  The handle-free entry points (slamk_dgemm_dev, slamk_pre_*,
- *     slamk_cholesky_inverse_dev, slamk_stage_gain_static_dev, slamk_mfma_f64_probe) run on the device that is
- *     current in the calling thread; their pointers must belong to it.
+ *     slamk_cholesky_inverse_dev, slamk_mfma_f64_probe) run on the device that is current in the calling thread;
+ *     their pointers must belong to it.  slamk_stage_gain_static_dev takes a handle and runs on the HANDLE's device
+ *     with that device's static workspace: W, L, Li, K, KR and r must live there, so the L / Li it is given must
+ *     come from a slamk_cholesky_inverse_dev call made while the handle's device was current.
  */
 #ifndef SLAMK_H
 #define SLAMK_H

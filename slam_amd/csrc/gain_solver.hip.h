@@ -878,17 +878,19 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
 // valid) into L and write inv(L) of the block into Li, one workgroup per matrix of the batch.  The inverse is
 // the forward solve above with the identity as right-hand side.
 // (registers capped at 128: two workgroups share a CU when a batch of mid-size filters factors its blocks together)
+// S points at the block's first element in matrix 0 of the batch and has its own leading dimension and batch stride
+// (the block may sit in a panel buffer instead of a square matrix); L and Li are addressed as square matrices.
 template <int MT>
-__global__ void __launch_bounds__(512, 4) chol_inv_block_kernel(const double* __restrict__ S, double* __restrict__ L,
-                                                              double* __restrict__ Li, int ld, long long sM, int j0,
-                                                              int* __restrict__ status)
+__global__ void __launch_bounds__(512, 4) chol_inv_block_kernel(const double* __restrict__ S, int ldS, long long sS,
+                                                              double* __restrict__ L, double* __restrict__ Li, int ld,
+                                                              long long sM, int j0, int* __restrict__ status)
 {
     extern __shared__ double lds[];                     // MT (MT + 1) / 2 tiles + one scratch tile
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const long long o = (long long)b * sM + (long long)j0 * ld + j0;
-    const double* Sb = S + o;
+    const double* Sb = S + (long long)b * sS;
     double* Lb = L + o;
     double* Lib = Li + o;
     const int blk = (wave + 7) & 7;
@@ -905,7 +907,7 @@ __global__ void __launch_bounds__(512, 4) chol_inv_block_kernel(const double* __
                 const int row = lk + 4 * r;
                 // the diagonal tiles are completed from their lower triangle
                 const int rr = (i == j && li > row) ? li : row, cc = (i == j && li > row) ? row : li;
-                tl[tsw(row, li)] = Sb[(long long)(16 * i + rr) * ld + 16 * j + cc];
+                tl[tsw(row, li)] = Sb[(long long)(16 * i + rr) * ldS + 16 * j + cc];
             }
         }
         if constexpr (decltype(with_y)::value) {

@@ -30,9 +30,6 @@
 #ifndef JOSEPH_STAMP
 #define JOSEPH_STAMP(i)    // timing builds (scripts/joseph_bench.hip) record the cycle counter of one workgroup here
 #endif
-#ifndef JOSEPH_STOP
-#define JOSEPH_STOP 0      // > 0: timing builds that leave the kernel after a phase
-#endif
 
 namespace slamk {
 
@@ -203,9 +200,6 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
         for (int kt = 0; kt < NT; ++kt) tile_ld4(lds + (blk * NT + kt) * 256, li, 4 * lk, af + 4 * kt);
     }
     __syncthreads();
-#if JOSEPH_STOP == 1
-    { double z = 0; if (active) for (int s = 0; s < 4 * NT; ++s) z += af[s]; if (form == 99) Pb[tid] = z; return; }
-#endif
 
     // ---- phase P: P tiles into LDS ------------------------------------------------------------------------
 #pragma unroll
@@ -217,9 +211,6 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
         }
     }
     __syncthreads();
-#if JOSEPH_STOP == 2
-    { double z = lds[tid]; if (active) for (int s = 0; s < 4 * NT; ++s) z += af[s]; if (form == 99) Pb[tid] = z; return; }
-#endif
 
     // Gate on the velocity correction and mean update (src/slam/main.cpp:229-232), as gain_apply_kernel: the work of
     // wavefront 4, which owns no row block up to NT = 7 and would otherwise wait at the next barrier through phase 1
@@ -263,9 +254,6 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
             for (int r = 0; r < 4; ++r) lds[(blk * NT + J) * 256 + tsw(lk + 4 * r, li)] = acc[J][r];
     }
     __syncthreads();
-#if JOSEPH_STOP == 3
-    { double z = lds[tid]; if (active) for (int s = 0; s < 4 * NT; ++s) z += af[s]; if (form == 99) Pb[tid] = z; return; }
-#endif
 
     if (form == 1) {       // P = (AP + AP^T) / 2
         for (int t = wave; t < NT * NT; t += 8) {
@@ -304,9 +292,6 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
             }
         }
     }
-#if JOSEPH_STOP == 4
-    { double z = 0; for (int t = 0; t < NT; ++t) z += o[t][0] + o[t][1] + o[t][2] + o[t][3]; if (form == 99) Pb[tid] = z; return; }
-#endif
     JOSEPH_STAMP(5);
     {
         // K R K^T: wavefront w < NT stages tile (w, chunk) of K; the next chunk is in flight during the products
@@ -373,9 +358,6 @@ __global__ void __launch_bounds__(512) joseph_kernel(FilterView fv, const double
                 }
         }
     }
-#if JOSEPH_STOP == 5
-    { double z = 0; for (int t = 0; t < NT; ++t) z += o[t][0] + o[t][1] + o[t][2] + o[t][3]; if (form == 99) Pb[tid] = z; return; }
-#endif
     JOSEPH_STAMP(6);
     if (!active) return;
     // Every tile goes out twice: as it is (rows of 128 bytes), and mirrored.  The mirror image is read back

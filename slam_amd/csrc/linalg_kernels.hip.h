@@ -29,6 +29,25 @@ __global__ void __launch_bounds__(256) symmetrize_kernel(const double* __restric
     }
 }
 
+// In place: the upper triangle of the nl x nl matrix P becomes the mirror image of its lower triangle (which is only
+// read).  grid (ceil(nl / 32), ceil(nl / 32)); blocks above the diagonal have nothing to do.
+__global__ void __launch_bounds__(256) mirror_lower_inplace_kernel(double* __restrict__ P, int ld, int nl)
+{
+    __shared__ double t[32][33];
+    if (blockIdx.y > blockIdx.x) return;
+    const int bi = blockIdx.x * 32, bj = blockIdx.y * 32;     // lower tile: rows bi.., columns bj..
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int i = bi + r, j = bj + tx;
+        t[r][tx] = (i < nl && j < nl) ? P[(long long)i * ld + j] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int i = bj + r, j = bi + tx;                    // element (i, j) of the upper tile = (j, i) of the lower
+        if (i < nl && j < nl && j > i) P[(long long)i * ld + j] = t[tx][r];
+    }
+}
+
 // dst[i][j] = src[i][j] for a rows x cols block (same ld and batch stride on both sides).
 __global__ void __launch_bounds__(256) copy_block_kernel(const double* __restrict__ src, double* __restrict__ dst,
                                                           int ld, long long stride, int rows, int cols)

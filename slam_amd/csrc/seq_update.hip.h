@@ -175,6 +175,10 @@ __device__ __forceinline__ void seq_update_filter(const FilterView& fv, int b, d
                 for (int k = 0; k < 4; ++k) v = fma(l4[k], ev[4 * g + k], v);
             }
             zv[i] = v;
+            // the diagonal of inv(L_c) is 1 / l_kk: a pivot of S_c that was not positive has made it NaN (or, at zero,
+            // infinite) -- the innovation covariance was not positive definite and no Cholesky gain exists
+            const double dinv = linv[tsw(i, i)];
+            if (!(dinv > 0.0 && dinv < 1.0e300)) atomicOr(fv.status + b, 2);
         }
         store_rows(buf ^ 1);
         __syncthreads();

@@ -480,29 +480,38 @@ int& inv_block_rows_ref()
 }
 int chol_outer_block() { return chol_outer_block_ref(); }
 #define INV_BS inv_block_rows_ref()
+// Where the symmetric matrix being factored lives: element (r, c) at p + (r - r0) * ld + (c - c0) (+ stride per matrix of
+// the batch).  A square matrix has r0 = c0 = 0; a panel buffer that holds the rows from r0 down of columns c0 .. has
+// ld = the panel's width.
+struct SymView {
+    double* p; int ld; long long stride; int r0, c0;
+    double* at(int r, int c) const { return p + (long long)(r - r0) * ld + (c - c0); }
+};
+
 template <int MT>
-int launch_chol_inv_block_t(slamk_handle* h, double* Sp, double* Lp, double* Lip, int ldm, long long sM, int B, int j0,
+int launch_chol_inv_block_t(slamk_handle* h, const SymView& S, double* Lp, double* Lip, int ldm, long long sM, int B, int j0,
                             int* status, hipStream_t st)
 {
     const size_t lds = ((size_t)MT * (MT + 1) / 2 + 1) * 256 * sizeof(double);
     { int rc_ = ensure_dynamic_lds(h, reinterpret_cast<const void*>(chol_inv_block_kernel<MT>), lds); if (rc_) return rc_; }
-    hipLaunchKernelGGL(chol_inv_block_kernel<MT>, dim3(B), dim3(512), lds, st, Sp, Lp, Lip, ldm, sM, j0, status);
+    hipLaunchKernelGGL(chol_inv_block_kernel<MT>, dim3(B), dim3(512), lds, st, S.at(j0, j0), S.ld, S.stride, Lp, Lip, ldm, sM,
+                       j0, status);
     return 0;
 }
 
 // diagonal block (nb x nb at (j0, j0), nb a multiple of 16 up to 128) of S -> L and inv(L)
-int launch_chol_inv_block(slamk_handle* h, double* Sp, double* Lp, double* Lip, int ldm, long long sM, int B, int j0,
+int launch_chol_inv_block(slamk_handle* h, const SymView& S, double* Lp, double* Lip, int ldm, long long sM, int B, int j0,
                           int nb, int* status, hipStream_t st)
 {
     switch (nb / 16) {
-        case 1: return launch_chol_inv_block_t<1>(h, Sp, Lp, Lip, ldm, sM, B, j0, status, st);
-        case 2: return launch_chol_inv_block_t<2>(h, Sp, Lp, Lip, ldm, sM, B, j0, status, st);
-        case 3: return launch_chol_inv_block_t<3>(h, Sp, Lp, Lip, ldm, sM, B, j0, status, st);
-        case 4: return launch_chol_inv_block_t<4>(h, Sp, Lp, Lip, ldm, sM, B, j0, status, st);
-        case 5: return launch_chol_inv_block_t<5>(h, Sp, Lp, Lip, ldm, sM, B, j0, status, st);
-        case 6: return launch_chol_inv_block_t<6>(h, Sp, Lp, Lip, ldm, sM, B, j0, status, st);
-        case 7: return launch_chol_inv_block_t<7>(h, Sp, Lp, Lip, ldm, sM, B, j0, status, st);
-        case 8: return launch_chol_inv_block_t<8>(h, Sp, Lp, Lip, ldm, sM, B, j0, status, st);
+        case 1: return launch_chol_inv_block_t<1>(h, S, Lp, Lip, ldm, sM, B, j0, status, st);
+        case 2: return launch_chol_inv_block_t<2>(h, S, Lp, Lip, ldm, sM, B, j0, status, st);
+        case 3: return launch_chol_inv_block_t<3>(h, S, Lp, Lip, ldm, sM, B, j0, status, st);
+        case 4: return launch_chol_inv_block_t<4>(h, S, Lp, Lip, ldm, sM, B, j0, status, st);
+        case 5: return launch_chol_inv_block_t<5>(h, S, Lp, Lip, ldm, sM, B, j0, status, st);
+        case 6: return launch_chol_inv_block_t<6>(h, S, Lp, Lip, ldm, sM, B, j0, status, st);
+        case 7: return launch_chol_inv_block_t<7>(h, S, Lp, Lip, ldm, sM, B, j0, status, st);
+        case 8: return launch_chol_inv_block_t<8>(h, S, Lp, Lip, ldm, sM, B, j0, status, st);
         default: return fail(h, SLAMK_EINVAL, "Cholesky diagonal block of %d rows", nb);
     }
 }
@@ -510,7 +519,7 @@ int launch_chol_inv_block(slamk_handle* h, double* Sp, double* Lp, double* Lip, 
 // Columns [J0, J1) of the blocked right-looking Cholesky of S (lower) into L, diagonal-block inverses into Li: the
 // trailing update after every diagonal block of NB rows only reaches the panel's own columns (rank NB).  On entry
 // these columns of S carry the updates of all columns left of J0.
-int chol_outer_panel(slamk_handle* h, double* Sp, double* Lp, double* Lip, int ldm, long long sM, int B, int ml, int J0,
+int chol_outer_panel(slamk_handle* h, const SymView& S, double* Lp, double* Lip, int ldm, long long sM, int B, int ml, int J0,
                      int J1, int* status, hipStream_t st)
 {
     const int NB = CHOL_NB;
@@ -518,22 +527,22 @@ int chol_outer_panel(slamk_handle* h, double* Sp, double* Lp, double* Lip, int l
         const int nb = std::min(NB, ml - j0);
         {
             ProfScope ps(h, PC_POTF2, st);
-            int rc = launch_chol_inv_block(h, Sp, Lp, Lip, ldm, sM, B, j0, nb, status, st);
+            int rc = launch_chol_inv_block(h, S, Lp, Lip, ldm, sM, B, j0, nb, status, st);
             if (rc) return rc;
         }
         const int rem = ml - j0 - nb;
         if (rem <= 0) break;
         ProfScope ps(h, PC_GEMM_CHOL, st);
         const long long o21 = (long long)(j0 + nb) * ldm + j0, o11 = (long long)j0 * ldm + j0;
-        const long long o22 = (long long)(j0 + nb) * ldm + (j0 + nb);
         // L21 = S21 inv(L11)^T
         HIPCHK(h, (launch_gemm<true, EPI_NONE, false, TRI_B_KLE_N>(
-                      gargs(Sp + o21, ldm, sM, Lip + o11, ldm, sM, Lp + o21, ldm, sM, rem, nb, nb), B, st)));
+                      gargs(S.at(j0 + nb, j0), S.ld, S.stride, Lip + o11, ldm, sM, Lp + o21, ldm, sM, rem, nb, nb), B, st)));
         // S22 -= L21 L21^T, lower tiles, columns of this outer panel only
         const int nin = J1 - (j0 + nb);
         if (nin > 0)
             HIPCHK(h, (launch_gemm<true, EPI_NONE, true, TRI_NONE>(
-                          gargs(Lp + o21, ldm, sM, Lp + o21, ldm, sM, Sp + o22, ldm, sM, rem, nin, nb, -1.0, 1.0), B, st)));
+                          gargs(Lp + o21, ldm, sM, Lp + o21, ldm, sM, S.at(j0 + nb, j0 + nb), S.ld, S.stride, rem, nin, nb, -1.0,
+                                1.0), B, st)));
     }
     return 0;
 }
@@ -541,11 +550,13 @@ int chol_outer_panel(slamk_handle* h, double* Sp, double* Lp, double* Lip, int l
 // Li = the inverses of L's diagonal blocks of INV_BS rows (all of inv(L) when ml <= INV_BS) from the inverses of its
 // diagonal NB-blocks, by recursive doubling on the block diagonal:
 //   inv([[A,0],[Bk,C]]) = [[inv A, 0], [-inv C * Bk * inv A, inv C]]
-// S's lower part is dead after the factorisation and holds the intermediate Bk * inv A.
+// The intermediate Bk * inv A of the pair whose lower block starts at row q is held in X at row q: in the same columns as
+// Bk when X is a square matrix like L (`compact` false: S, whose lower part is dead after the factorisation, serves),
+// from column 0 when X is a buffer of ml rows and INV_BS / 2 columns (`compact`).
 // The doubling stops at blocks of INV_BS rows: gain_from_factor runs the two triangular solves block-wise with
 // these diagonal-block inverses, so the levels above (most of the cost of a full inverse) are never built.
-int chol_block_inverses(slamk_handle* h, double* Sp, double* Lp, double* Lip, int ldm, long long sM, int B, int ml,
-                        hipStream_t st)
+int chol_block_inverses(slamk_handle* h, double* Xp, int ldx, long long sX, bool compact, double* Lp, double* Lip, int ldm,
+                        long long sM, int B, int ml, hipStream_t st)
 {
     ProfScope ps_inv(h, PC_GEMM_CHOL, st);
     for (int s = CHOL_NB; s < std::min(ml, INV_BS); s *= 2) {
@@ -558,16 +569,25 @@ int chol_block_inverses(slamk_handle* h, double* Sp, double* Lp, double* Lip, in
             const long long oA = (long long)base * ldm + base;               // top-left block (s x s)
             const long long oB = (long long)(base + s) * ldm + base;         // bottom-left (M x s)
             const long long oC = (long long)(base + s) * ldm + (base + s);   // bottom-right (M x M)
-            const long long s2 = (long long)2 * s * (ldm + 1);
-            GemmArgs g1 = gargs(Lp + oB, ldm, sM, Lip + oA, ldm, sM, Sp + oB, ldm, sM, M, s, s);
-            g1.sA2 = g1.sB2 = g1.sC2 = s2; g1.nb2 = cnt;
+            const long long oX = (long long)(base + s) * ldx + (compact ? 0 : base);
+            const long long s2 = (long long)2 * s * (ldm + 1), s2x = (long long)2 * s * ldx + (compact ? 0 : 2 * s);
+            GemmArgs g1 = gargs(Lp + oB, ldm, sM, Lip + oA, ldm, sM, Xp + oX, ldx, sX, M, s, s);
+            g1.sA2 = g1.sB2 = s2; g1.sC2 = s2x; g1.nb2 = cnt;
             HIPCHK(h, (launch_gemm<false, EPI_NONE, false, TRI_B_KGE_N>(g1, B * cnt, st)));
-            GemmArgs g2 = gargs(Lip + oC, ldm, sM, Sp + oB, ldm, sM, Lip + oB, ldm, sM, M, s, M, -1.0, 0.0);
-            g2.sA2 = g2.sB2 = g2.sC2 = s2; g2.nb2 = cnt;
+            GemmArgs g2 = gargs(Lip + oC, ldm, sM, Xp + oX, ldx, sX, Lip + oB, ldm, sM, M, s, M, -1.0, 0.0);
+            g2.sA2 = g2.sC2 = s2; g2.sB2 = s2x; g2.nb2 = cnt;
             HIPCHK(h, (launch_gemm<false, EPI_NONE, false, TRI_A_KLE_M>(g2, B * cnt, st)));
         }
     }
     return 0;
+}
+
+// columns of the compact scratch of chol_block_inverses for a matrix of ml rows: the widest lower-left block it forms
+int inverse_scratch_cols(int ml)
+{
+    int w = CHOL_NB;
+    for (int s = CHOL_NB; s < std::min(ml, INV_BS); s *= 2) w = s;
+    return w;
 }
 
 // S (lower) -> L (Cholesky factor) and Li = the inverses of L's diagonal blocks of INV_BS rows (all of inv(L) when
@@ -581,7 +601,7 @@ int cholesky_inverse(slamk_handle* h, double* Sp, double* Lp, double* Lip, int l
     // complete, which reads and writes the large trailing matrix OB / CHOL_NB times less often.
     for (int J0 = 0; J0 < ml; J0 += OB) {
         const int J1 = std::min(ml, J0 + OB);
-        int rc = chol_outer_panel(h, Sp, Lp, Lip, ldm, sM, B, ml, J0, J1, status, st);
+        int rc = chol_outer_panel(h, SymView{Sp, ldm, sM, 0, 0}, Lp, Lip, ldm, sM, B, ml, J0, J1, status, st);
         if (rc) return rc;
         const int remo = ml - J1;
         if (remo > 0) {          // the rest of the trailing matrix: one update of rank J1 - J0
@@ -592,7 +612,7 @@ int cholesky_inverse(slamk_handle* h, double* Sp, double* Lp, double* Lip, int l
                           B, st)));
         }
     }
-    return chol_block_inverses(h, Sp, Lp, Lip, ldm, sM, B, ml, st);
+    return chol_block_inverses(h, Sp, ldm, sM, false, Lp, Lip, ldm, sM, B, ml, st);
 }
 
 // K = W S^-1 = (W L^-T) L^-1 and K R from the factor L and the inverses Li of its diagonal INV_BS-blocks, as two
@@ -990,6 +1010,33 @@ double gemm_flops(int M, int N, int K, bool lower, int tri)
             f += 2.0 * std::min(BM, M - m0) * std::min(BN, N - n0) * std::max(0, ke - kb);
         }
     return f;
+}
+
+// update_form = 2 only exists for filters whose covariance fits LDS: checked at the entry of every call that runs an
+// update, before anything is queued (features arrive with the frames, so a running filter can grow past the limit)
+int check_update_form(slamk_handle* h)
+{
+    if (h->prm.update_form == 2 && max_nl(h) > 16 * SEQ_MAX_NT)
+        return fail(h, SLAMK_EINVAL, "update_form 2 (block-sequential) needs n <= %d, got %d", 16 * SEQ_MAX_NT, max_nl(h));
+    return 0;
+}
+
+// Frame begin (old_pos = X, depth clamp) for the filters of the batch that have not had theirs yet, one launch per run of
+// such filters: only taken when SOME filters were begun by slamk_frame(b, ...) -- their old_pos must stay what it was
+// before any state override (src/slam/main.cpp:168 comes before :180-185).
+int begin_remaining(slamk_handle* h, hipStream_t st)
+{
+    for (int b = 0; b < h->B;) {
+        if (h->begun[b]) { ++b; continue; }
+        int e = b;
+        while (e < h->B && !h->begun[e]) ++e;
+        const Range rg = make_range(h, b, e - b);
+        hipLaunchKernelGGL(frame_begin_kernel, dim3(e - b), dim3(256), 0, st, rg.fv, -1);
+        b = e;
+    }
+    HIPCHK(h, hipGetLastError());
+    h->mark_begun(0, h->B);
+    return 0;
 }
 
 }  // namespace
@@ -1459,6 +1506,7 @@ int slamk_update_dev(slamk_handle* h, const double* qbw_dev, const double* alt_d
 {
     if (!h || !qbw_dev) return SLAMK_EINVAL;
     if (!alt_dev && !h->prm.use_alt_override) return fail(h, SLAMK_EINVAL, "update: alt required without alt_override");
+    { int rc_ = check_update_form(h); if (rc_) return rc_; }
     ENTER(h);
     { int rc_ = ensure_workspaces(h); if (rc_) return rc_; }
     note_stream(h, stream);
@@ -1476,13 +1524,16 @@ int slamk_step_dev(slamk_handle* h, const double* qbw_dev, const double* w_dev, 
 {
     if (!h || !qbw_dev || !w_dev || !acc_dev || !dt_dev) return SLAMK_EINVAL;
     if (!alt_dev && !h->prm.use_alt_override) return fail(h, SLAMK_EINVAL, "step: alt required without alt_override");
+    { int rc_ = check_update_form(h); if (rc_) return rc_; }
     ENTER(h);
     { int rc_ = ensure_workspaces(h); if (rc_) return rc_; }
     hipStream_t st = (hipStream_t)stream;
     note_stream(h, stream);
     // slamk_frame / slamk_frame_begin_dev of this iteration have already set old_pos and clamped the depths; a
     // state override between them and this call (UPDATE_POS, src/slam/main.cpp:180-185) must not move old_pos,
-    // which the reference takes before the override (:168)
+    // which the reference takes before the override (:168).  Per filter: when only some filters have been begun, the
+    // others get their frame begin here, in launches of their own, and the step itself runs none.
+    if (h->nbegun > 0 && h->nbegun < h->B) { int rc_ = begin_remaining(h, st); if (rc_) return rc_; }
     const bool frame_begin = h->nbegun < h->B;
     if (h->graph_mode && !h->prof_on && st != nullptr) {
         // replay (or first capture) the launch sequence as one hipGraph: one submission per iteration
@@ -1598,6 +1649,7 @@ int slamk_update(slamk_handle* h, const double* qbw, const double* alt, int* app
 {
     if (!h || !qbw) return SLAMK_EINVAL;
     if (!alt && !h->prm.use_alt_override) return fail(h, SLAMK_EINVAL, "update: alt required without alt_override");
+    { int rc_ = check_update_form(h); if (rc_) return rc_; }
     ENTER_HOST(h);
     { int rc_ = ensure_workspaces(h); if (rc_) return rc_; }
     const size_t B = h->B;
@@ -1840,8 +1892,9 @@ struct slamk_sharded {
     void* ag_ctx = nullptr;
     int n = 0, m = 0, bn = 0, bm = 0, N = 0, M = 0, r0 = 0, q0 = 0;
     double *P = nullptr, *G1 = nullptr, *G2 = nullptr, *AP = nullptr, *W = nullptr, *K = nullptr, *Y = nullptr,
-           *KR = nullptr, *S = nullptr, *Lm = nullptr, *Li = nullptr, *rfull = nullptr, *U = nullptr, *halo = nullptr, *ws = nullptr;
+           *KR = nullptr, *X = nullptr, *Lm = nullptr, *Li = nullptr, *rfull = nullptr, *U = nullptr, *halo = nullptr, *ws = nullptr;
     size_t U_elems = 0, ws_elems = 0;
+    int ldx = 0;        // X: M rows x min(M, INV_BS) / 2 columns, intermediates of the diagonal-block inverses
     std::vector<void*> allocs;
 };
 
@@ -2000,7 +2053,9 @@ int slamk_sharded_load_cov_dev(slamk_sharded* s, const double* P_full_dev, int l
     s->U_elems = (M + 16 * (size_t)g) * std::min<size_t>(M, chol_outer_block());
     rc |= alloc(&s->P, bn * N); rc |= alloc(&s->G1, N * N); rc |= alloc(&s->G2, N * N);
     rc |= alloc(&s->AP, bn * N); rc |= alloc(&s->W, N * M); rc |= alloc(&s->K, N * M); rc |= alloc(&s->Y, bn * M);
-    rc |= alloc(&s->KR, bn * M); rc |= alloc(&s->S, M * M); rc |= alloc(&s->Lm, M * M); rc |= alloc(&s->Li, M * M);
+    // (S = H W + R only ever exists one gathered panel at a time, in U)
+    s->ldx = inverse_scratch_cols((int)M);
+    rc |= alloc(&s->KR, bn * M); rc |= alloc(&s->X, M * (size_t)s->ldx); rc |= alloc(&s->Lm, M * M); rc |= alloc(&s->Li, M * M);
     rc |= alloc(&s->rfull, M); rc |= alloc(&s->U, s->U_elems); rc |= alloc(&s->halo, (size_t)g * HALO_ROWS * N);
     // partial products of the GEMMs whose k range is cut into slices (a rank's rows are few, the k ranges long)
     s->ws_elems = std::max(8 * (s->U_elems / g), 4 * bn * std::min<size_t>(M, INV_BS));
@@ -2074,12 +2129,13 @@ static int sharded_cholesky(slamk_sharded* s, hipStream_t st)
         }
         int rc = sharded_allgather(s, s->U, (size_t)chunk * ob, st);
         if (rc) return rc;
-        HIPCHK(h, hipMemcpy2DAsync(s->S + (size_t)J0 * M + J0, (size_t)M * sizeof(double), s->U, (size_t)ob * sizeof(double),
-                                   (size_t)ob * sizeof(double), R, hipMemcpyDeviceToDevice, st));
-        rc = chol_outer_panel(h, s->S, s->Lm, s->Li, M, 0, 1, M, J0, J1, h->fv.status, st);
+        // the gathered panel is factored where it lies: rows J0 .. M - 1 of columns [J0, J1), leading dimension ob
+        rc = chol_outer_panel(h, SymView{s->U, ob, 0, J0, J0}, s->Lm, s->Li, M, 0, 1, M, J0, J1, h->fv.status, st);
         if (rc) return rc;
     }
-    return chol_block_inverses(h, s->S, s->Lm, s->Li, M, 0, 1, M, st);
+    if (inverse_scratch_cols(M) > s->ldx)
+        return fail(h, SLAMK_EINVAL, "sharded: the block sizes changed since the covariance was loaded");
+    return chol_block_inverses(h, s->X, s->ldx, 0, true, s->Lm, s->Li, M, 0, 1, M, st);
 }
 
 int slamk_sharded_update_dev(slamk_sharded* s, const double* qbw_dev, const double* alt_dev, const double* src_dev,
@@ -2099,8 +2155,8 @@ int slamk_sharded_update_dev(slamk_sharded* s, const double* qbw_dev, const doub
     const int ml = std::min(max_ml(h), s->M);
     hipLaunchKernelGGL(fill_kernel, dim3((s->M + 255) / 256), dim3(256), 0, st, s->rfull, s->M, 1.0);
     HIPCHK(h, hipMemcpyAsync(s->rfull, h->fv.rdiag, (size_t)ml * sizeof(double), hipMemcpyDeviceToDevice, st));
-    HIPCHK(h, hipMemsetAsync(s->Lm, 0, M * M * sizeof(double), st));
-    HIPCHK(h, hipMemsetAsync(s->Li, 0, M * M * sizeof(double), st));
+    // (Lm and Li are zero above the diagonal since they were allocated: the factorisation writes the lower part and
+    // zeros, never anything else, above it)
     rc = sharded_cholesky(s, st);
     if (!rc) rc = gain_from_factor(h, s->W + r0 * M, s->Y, s->K + r0 * M, s->KR, s->M, 0, s->Lm, s->Li, s->M, 0, s->rfull, 0,
                                    s->bn, s->M, 1, st, s->ws, s->ws_elems);                                    // K_r, K_r R
@@ -2110,6 +2166,10 @@ int slamk_sharded_update_dev(slamk_sharded* s, const double* qbw_dev, const doub
     HIPCHK(h, hipMemcpyAsync(s->G1 + r0 * N, s->P, bn * N * sizeof(double), hipMemcpyDeviceToDevice, st));
     rc = sharded_allgather(s, s->G1, bn * N, st);
     if (rc) return rc;
+    // entries (i, j) and (j, i) of the propagated covariance come from different ranks' products: the lower triangle
+    // is mirrored so that the update works on an exactly symmetric P on every rank (the reference symmetrises after
+    // every update, src/slam/main.cpp:567)
+    hipLaunchKernelGGL(mirror_lower_inplace_kernel, dim3((s->N + 31) / 32, (s->N + 31) / 32), dim3(256), 0, st, s->G1, s->N, s->N);
     const double* Ar = s->G2 + r0 * N;
     // P_r <- (A_r P) A^T + (K_r R) K^T
     HIPCHK(h, (launch_gemm<false, EPI_NONE, false, TRI_NONE>(gargs(Ar, s->N, 0, s->G1, s->N, 0, s->AP, s->N, 0, s->bn, s->N, s->N), 1, st)));
@@ -2130,6 +2190,8 @@ int slamk_sharded_gather_cov_dev(slamk_sharded* s, double* P_full_dev, int ld, v
     HIPCHK(h, hipMemcpyAsync(s->G1 + (size_t)s->r0 * N, s->P, bn * N * sizeof(double), hipMemcpyDeviceToDevice, st));
     int rc = sharded_allgather(s, s->G1, bn * N, st);
     if (rc) return rc;
+    // the row blocks of the Joseph update come from different ranks: hand out the symmetric completion of the lower part
+    hipLaunchKernelGGL(mirror_lower_inplace_kernel, dim3((s->N + 31) / 32, (s->N + 31) / 32), dim3(256), 0, st, s->G1, s->N, s->N);
     HIPCHK(h, hipMemcpy2DAsync(P_full_dev, (size_t)ld * sizeof(double), s->G1, N * sizeof(double), (size_t)s->n * sizeof(double),
                                s->n, hipMemcpyDeviceToDevice, st));
     return SLAMK_OK;

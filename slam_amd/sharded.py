@@ -20,9 +20,8 @@ which restates `calcP`, `calcK`, `updateP` (Joseph form) and the gated mean upda
 (src/slam/main.cpp:526-530, 539-552, 561-569, 228-232) for a row-distributed P.
 
 `ShardedFilter` is the product path: the sequence above inside libslamk.so (slamk_sharded_*, RCCL all-gathers on the
-caller's stream), which fails without a GPU.  `ShardedLargeMapFilter` is the same sequence written out over a backend
-object and `torch.distributed`: tests inject a CPU backend to rehearse the sharding and the collectives with several
-ranks under `gloo`, where no GPU exists.
+caller's stream), which fails without a GPU.  (The CPU rehearsal of the same sequence over `gloo` is test
+infrastructure and lives in tests/sharded_rehearsal.py.)
 """
 import ctypes as C
 
@@ -140,140 +139,3 @@ class ShardedFilter:
 
     def sync(self):
         self.fb.sync(self.sptr)
-
-
-class ShardedLargeMapFilter:
-    """The sequence of the module docstring over a backend object (CPU rehearsal of the sharding; the product path is
-    ShardedFilter).  `panel`: columns per panel of the factorisation (the library's outer block size)."""
-
-    F, H = 0, 1
-    HALO = 13
-
-    def __init__(self, backend, rank=0, world=1, group=None, panel=512):
-        self.be, self.rank, self.world, self.group = backend, rank, world, group
-        self.panel = panel
-        self.n = self.m = 0
-        self.P = None
-
-    # -- layout ------------------------------------------------------------------------------
-    def _layout(self):
-        n, m = self.be.dims()
-        g = self.world
-        self.n, self.m = n, m
-        self.bn = _pad16((_pad16(n) + g - 1) // g)      # rows of P per rank
-        self.bm = _pad16((_pad16(m) + g - 1) // g)
-        self.N, self.M = self.bn * g, self.bm * g       # padded global dimensions
-        self.r0 = self.rank * self.bn
-
-    def load_cov(self, P_full):
-        """Distribute a full n x n covariance (same on every rank): keep rows [r0, r0 + bn)."""
-        self._layout()
-        be = self.be
-        self.P = be.empty(self.bn, self.N)
-        hi = min(self.n, self.r0 + self.bn)
-        if hi > self.r0:
-            self.P[:hi - self.r0, :self.n] = P_full[self.r0:hi, :self.n]
-        self.G1 = be.empty(self.N, self.N)          # T (own rows and the rows received), then gathered P
-        self.G2 = be.empty(self.N, self.N)          # A
-        self.AP = be.empty(self.bn, self.N)
-        self.W = be.empty(self.N, self.M)
-        self.K = be.empty(self.N, self.M)
-        self.Y = be.empty(self.bn, self.M)
-        self.KR = be.empty(self.bn, self.M)
-        self.S = be.empty(self.M, self.M)           # the panels as they are factored (never S as a whole)
-        self.Lm = be.empty(self.M, self.M)
-        self.Li = be.empty(self.M, self.M)
-        self.rfull = be.empty(1, self.M)[0]
-
-    def _all_gather(self, full, block_rows, mine=None):
-        """Rows [rank * block_rows, ...) of `full` from every rank (`mine`: this rank's block if it lives elsewhere)."""
-        own = full[self.rank * block_rows:(self.rank + 1) * block_rows]
-        if mine is not None:
-            own.copy_(mine)
-        if self.world == 1:
-            return
-        import torch.distributed as dist
-        if full.is_cuda and dist.get_backend(self.group) != "nccl":
-            # rehearsal on a backend without device collectives (gloo): stage through host memory
-            host = torch.empty(full.shape, dtype=full.dtype)
-            dist.all_gather_into_tensor(host, own.cpu().contiguous(), group=self.group)
-            full.copy_(host)
-            return
-        dist.all_gather_into_tensor(full, own.contiguous(), group=self.group)
-
-    def gather_cov(self):
-        """Full n x n covariance on every rank."""
-        full = self.be.empty(self.N, self.N)
-        self._all_gather(full, self.bn, self.P)
-        return full[:self.n, :self.n]
-
-    # -- loop body ---------------------------------------------------------------------------
-    def _halo_rows(self, p):
-        """Global rows of T in the 13 slots of rank p's pack (-1: not owned by p): the first and the last two rows of
-        its block (a feature's triple may lie across a block boundary), rows 0..5 (position, velocity) and the bias
-        triple: everything a row of F outside the block can refer to."""
-        bn, bias0 = self.bn, self.n - 3
-        cand = [p * bn, p * bn + 1, (p + 1) * bn - 2, (p + 1) * bn - 1, 0, 1, 2, 3, 4, 5, bias0, bias0 + 1, bias0 + 2]
-        return [r if p * bn <= r < (p + 1) * bn else -1 for r in cand]
-
-    def predict(self, qbw, w, acc, dt):
-        be = self.be
-        be.motion(qbw, w, acc, dt)
-        r = slice(self.r0, self.r0 + self.bn)
-        be.right(self.F, self.G1[r], self.P)                        # T_r = P_r F^T
-        if self.world > 1:
-            pack = be.empty(self.world * self.HALO, self.N)
-            for t, row in enumerate(self._halo_rows(self.rank)):
-                if row >= 0:
-                    pack[self.rank * self.HALO + t] = self.G1[row]
-            self._all_gather(pack, self.HALO)
-            for p in range(self.world):
-                if p != self.rank:
-                    for t, row in enumerate(self._halo_rows(p)):
-                        if row >= 0:
-                            self.G1[row] = pack[p * self.HALO + t]
-        be.left(self.F, self.P, self.r0, self.G1, True)             # P_r = F_r T + Q_r
-
-    def _cholesky(self):
-        """S = H W + R = L L^T, every rank ending with L and the inverses of its diagonal blocks."""
-        be, g, M = self.be, self.world, self.M
-        for J0 in range(0, M, self.panel):
-            J1 = min(M, J0 + self.panel)
-            ob, R = J1 - J0, M - J0
-            chunk = _pad16((R + g - 1) // g)            # rows of the panel per rank
-            U = be.empty(g * chunk, ob)
-            row0 = J0 + self.rank * chunk
-            rows = max(0, min(M, row0 + chunk) - row0)
-            if rows > 0:
-                Ur = U[self.rank * chunk:self.rank * chunk + rows]
-                rop = be.left(self.H, Ur, row0, self.W[:, J0:J1], True, col0=J0)    # rows of H W + R
-                for q in range(row0 + rop, row0 + rows):                           # rows the operator does not have
-                    if J0 <= q < J1:
-                        Ur[q - row0, q - J0] = 1.0
-                if J0 > 0:
-                    be.gemm(Ur, self.Lm[row0:row0 + rows, :J0], self.Lm[J0:J1, :J0], True, alpha=-1.0, beta=1.0)
-            self._all_gather(U, chunk)
-            self.S[J0:M, J0:J1] = U[:R]
-            be.chol_panel(self.S, self.Lm, J0, J1)
-        be.block_inverses(self.Lm, self.Li)
-
-    def update(self, qbw, src=None, refl=None):
-        be, m = self.be, self.m
-        e, rd = be.measure(qbw, src, refl)
-        r = slice(self.r0, self.r0 + self.bn)
-        be.right(self.H, self.W[r], self.P)                         # W_r = P_r H^T
-        self._all_gather(self.W, self.bn)
-        ml = min(_pad16(m), rd.shape[0])
-        self.rfull.fill_(1.0)                                       # unit diagonal on the rows the operator does not have
-        self.rfull[:ml] = rd[:ml]
-        self.Lm.zero_()
-        self.Li.zero_()
-        self._cholesky()
-        be.gain(self.Y, self.K[r], self.KR, self.W[r], self.Lm, self.Li, self.rfull)   # K_r = W_r S^-1, K_r R
-        self._all_gather(self.K, self.bn)
-        be.eye_minus_kh(self.G2, self.K, 0)                         # A = I - K H, all rows, on every rank
-        self._all_gather(self.G1, self.bn, self.P)
-        be.gemm(self.AP, self.G2[r], self.G1, False)                # A_r P
-        be.gemm(self.P, self.AP, self.G2, True)                     # (A_r P) A^T
-        be.gemm(self.P, self.KR, self.K, True, alpha=1.0, beta=1.0)  # + (K_r R) K^T
-        return be.apply(self.K)                                     # dx = K e, gate, mean update (replicated)

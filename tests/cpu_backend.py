@@ -1,4 +1,4 @@
-"""CPU backend of slam_amd.sharded.ShardedLargeMapFilter (TEST INFRASTRUCTURE): the local operations of the
+"""CPU backend of tests/sharded_rehearsal.ShardedLargeMapFilter (TEST INFRASTRUCTURE): the local operations of the
 row-block sharded filter done with the oracle and torch CPU tensors, so that the sharding logic and
 the collectives can run under gloo without a GPU."""
 import numpy as np

@@ -122,6 +122,7 @@ def test_large_map_2000_features_row_block_sharded_against_golden():
                 float(np.max(np.abs(P[si, sj] - g["sampleP"][k - 1]) / np.sqrt(d[si] * d[sj]))),
                 float(np.max(np.abs(P - P.T)) / np.max(d))]
         assert np.all(np.isfinite(P)) and max(errs) < TOL, (k, errs)
+        assert np.array_equal(P, P.T)
         worst = max(worst, max(errs))
     print("2000 features, row-block sharded: worst deviation from the golden values %.2e" % worst)
     sh.close()

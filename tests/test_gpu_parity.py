@@ -35,6 +35,11 @@ def compare_snaps(so, sg, tol=TOL):
             e = helpers.rel_err(b[key], a[key])
             assert e < tol, "step %d %s rel err %.3e" % (k, key, e)
             worst = max(worst, e)
+        # entry-wise as well (every entry of P against sqrt(P_ii P_jj)): a norm-wise bound alone would let the small
+        # cross terms, e.g. those of the 1e-4 bias block, be wrong
+        e = helpers.entry_err(b["P"], a["P"])
+        assert e < tol, "step %d P entry-wise err %.3e" % (k, e)
+        worst = max(worst, e)
         assert "%0.5f,%0.5f" % a["xy"] == "%0.5f,%0.5f" % b["xy"]
     return worst
 
@@ -488,19 +493,23 @@ def test_error_paths():
         fb.set_cov(0, np.eye(9))            # n must match the feature count
 
 
-@pytest.mark.parametrize("nf", [3, 60])
-def test_indefinite_innovation_covariance_is_reported(nf):
+@pytest.mark.parametrize("nf,form,batch", [(3, 0, 2), (60, 0, 2), (3, 2, 2), (20, 2, 2), (3, 2, 300), (20, 2, 300)])
+def test_indefinite_innovation_covariance_is_reported(nf, form, batch):
     """A covariance that is not positive semi-definite makes S = H P H^T + R indefinite: the Cholesky gain does
-    not exist and slamk_sync says so (small fused path and blocked large path)."""
-    fb = ekf.FilterBatch(max_features=nf, batch=2)
+    not exist and slamk_sync says so (small fused path and blocked large path; in the block-sequential form, whose
+    16 x 16 innovation blocks are factored one by one, through both of its kernels: the separate update kernel and,
+    for batches of up to 256 filters, the one-launch step)."""
+    p = ekf.default_params()
+    p.update_form = form
+    fb = ekf.FilterBatch(max_features=nf, batch=batch, params=p)
     q = [0, 0, 0, 1]
     fb.frame(-1, [(i + 1, 0.05 * i - 0.1, 0.02 * i, 0, 0) for i in range(nf)], q)
     n = 9 + 3 * nf
     fb.set_cov(1, -50.0 * np.eye(n))
-    fb.predict(np.tile(q, 2), np.zeros(6), np.zeros(6), [0.03, 0.03])
+    fb.predict(np.tile(q, batch), np.zeros(3 * batch), np.zeros(3 * batch), [0.03] * batch)
     with pytest.raises(ekf.SlamkError) as ei:
-        fb.update(np.tile(q, 2))
-    assert ei.value.code == _lib.SLAMK_ENOTSPD and "filter 1" in str(ei.value)
+        fb.update(np.tile(q, batch))
+    assert ei.value.code == _lib.SLAMK_ENOTSPD and "filter 1 (1 of %d" % batch in str(ei.value)
     fb.close()
 
 
@@ -668,6 +677,7 @@ def test_sharded_filter_single_rank(rccl, blocks):
     P, sv, applied, dims = _run_sharded(0, 1, None, nf, steps, torch.device("cuda", 0), rccl_single_rank=rccl, blocks=blocks)
     assert applied == [s["applied"] for s in so if s["applied"] >= 0]
     assert helpers.rel_err(P, f.P) < TOL and helpers.entry_err(P, f.P) < TOL
+    assert np.array_equal(P, P.T)
     assert helpers.rel_err(sv, f.state_vector()) < TOL
     assert dims["n"] == 9 + 3 * nf and dims["rows_per_rank"] == dims["n_padded"]
 
@@ -710,4 +720,6 @@ def test_sharded_filter_several_ranks_on_one_gpu(tmp_path, world, nf, blocks):
     n = 9 + 3 * nf
     assert helpers.rel_err(res[:n * n].reshape(n, n), f.P) < TOL
     assert helpers.entry_err(res[:n * n].reshape(n, n), f.P) < TOL
+    # rows of different ranks come from different products: the gathered covariance is still exactly symmetric
+    assert np.array_equal(res[:n * n].reshape(n, n), res[:n * n].reshape(n, n).T)
     assert helpers.rel_err(res[n * n:], f.state_vector()) < TOL

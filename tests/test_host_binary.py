@@ -4,6 +4,7 @@ import os
 import subprocess
 import tempfile
 
+import numpy as np
 import pytest
 
 from oracle import oracle as orc
@@ -84,7 +85,14 @@ def test_host_type_mirrors_against_the_device():
     lines = r.stdout.strip().split("\n")
     assert lines[0].startswith("rows 11:") and lines[1] == "refl flags 1 0"
     assert "nf 3 rf 1 nrf 2 rows 18" in lines
-    assert lines[-3].startswith("id 10 pib 0 -0.05 0.01 anchor 0.5 -0.25 1.34 q0w 0.99") and lines[-2].split()[-1] == "1"
+    ids = [l for l in lines if l.startswith("id ")]
+    assert ids[0].startswith("id 10 pib 0 -0.05 0.01 anchor 0.5 -0.25 1.34 q0w 0.99") and ids[1].split()[-1] == "1"
+    # States::dynamics and Feature::pib0Hat / ppbHat + View::subtract / toMat on the host (src/ARC/states.cpp:222-263,
+    # src/ARC/feature.cpp:143-198, src/ARC/view.cpp:3-47) against the device's predict and innovation of the same iteration
+    dyn = [l for l in lines if l.startswith("dynamics mirror:")][0]
+    inn = [l for l in lines if l.startswith("innovation mirror:")][0]
+    assert float(dyn.split()[-1]) < 1e-14, dyn
+    assert inn.split()[3] == "15" and float(inn.split()[-1]) < 1e-13, inn
 
 
 def test_host_type_mirrors_compile_and_flatten_like_the_reference():
@@ -96,6 +104,20 @@ def test_host_type_mirrors_compile_and_flatten_like_the_reference():
     exp = [-1.34 + 1.30, 0.1 - 0.11, 0.2 - 0.19, 0.3 - 0.29, 0.4 - 0.41, 0.5 - 0.52, 0.6 - 0.57, 1.1 - 1.0, 1.2 - 1.0,
            1.3 - 1.0, 1.4 - 1.0]
     assert vals == exp
+    out = {l.split(":")[0]: l.split(":")[1].split() for l in r.stdout.strip().split("\n") if ":" in l}
+    # States(kx), operator+=, operator*= (b is neither read from kx nor scaled) and dynamics (src/ARC/states.cpp:6-37,
+    # 69-86, 222-263); Feature::xibHat / pib0Hat / ppbHat (src/ARC/feature.cpp:143-198) with identity attitudes
+    assert out["value add"] == "nf 2 X 33 V 5 f1 0.62 b 0.5 id 8".split()
+    assert [float(x) for x in out["value scale"][1::2]] == [5.5, 0.2, 0.5]
+    dv = out["value dynamics"]
+    assert float(dv[1]) == 2.75 and float(dv[3]) == 1.25 and float(dv[-1]) == 0
+    p0, p1, p2, V, w = 0.2, 0.4, 0.35, (5.0, 5.5, 6.25), (0.1, 0.2, 0.3)
+    rates = [(-V[1] + p0 * V[0]) * p2 + p1 * w[0] - (1 + p0 * p0) * w[2] + p0 * p1 * w[1],
+             (-V[2] + p1 * V[0]) * p2 - p0 * w[0] + (1 + p1 * p1) * w[1] - p0 * p1 * w[2],
+             (-w[2] * p0 + w[1] * p1) * p2 + V[0] * p2 * p2]
+    assert np.allclose([float(x) for x in dv[5:8]], [0.5 * x for x in rates], rtol=1e-15, atol=0)
+    hat = [float(x) for x in out["hat"] if x[0] in "-0123456789"]
+    assert np.allclose(hat, [20, 2, 4, 2.5 / 20.5, 4.5 / 20.5, 0.1, (-4 - 2.68) / 20], rtol=1e-15, atol=0)
 
 
 @pytest.mark.gpu

@@ -3,6 +3,7 @@ import os
 import tempfile
 
 import numpy as np
+import pytest
 
 from oracle import oracle as orc
 from slam_amd import synth
@@ -136,11 +137,14 @@ def test_bench_cpu_baseline_leg_runs_on_a_small_sample():
     assert "sample" in r
 
 
-def test_numpy_algebra_oracle_matches_the_c_loops():
+@pytest.mark.parametrize("nf,steps", [(40, 13), (200, 7)])
+def test_numpy_algebra_oracle_matches_the_c_loops(nf, steps):
     """oracle/numpy_oracle.py (LAPACK products and LU solve around the C per-feature parts, used for the 2000-feature
-    golden) against orc_step's own dense loops on a stream with churn."""
+    golden) against orc_step's own dense loops on a stream with churn; at 200 features (n = 609, m = 1001) LAPACK's
+    blocked code paths are the ones that run."""
     from oracle import numpy_oracle as npo
-    st = synth.gen_stream(seed=2, nf=40, steps=13, churn=True, drop_at=6, drop_count=2, add_at=9, add_count=3)
+    st = synth.gen_stream(seed=2, nf=nf, steps=steps, churn=True, drop_at=steps // 2, drop_count=2, add_at=steps - 4,
+                          add_count=3)
     inp = helpers.stream_inputs(st, 7)
     fs = []
     for mode in (0, 1):

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the row-block sharded large-map filter (slam_amd/sharded.py) with
+"""CPU, world_size 2 over gloo: the row-block sharded large-map sequence (tests/sharded_rehearsal.py) with
 the oracle as local backend must reproduce the oracle's own single-process run."""
 import os
 import socket
@@ -30,7 +30,7 @@ def _worker(rank, world, port, nf, steps, panel, out):
     try:
         from oracle import oracle as orc
         from slam_amd import synth
-        from slam_amd.sharded import ShardedLargeMapFilter
+        from sharded_rehearsal import ShardedLargeMapFilter
         from cpu_backend import OracleBackend
         import helpers
         st = synth.gen_stream(seed=11, nf=nf, steps=steps, churn=False)
