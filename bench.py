@@ -31,6 +31,17 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X: 256 CU x 2.4 GHz x 128 fp64 FLOP/clk/
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E
 
 
+def kernel_source_sha256():
+    """Hash of slam_amd/csrc (the same as scripts/pmc_summarize.py stores beside the counters it collects)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "slam_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
 def build_inputs(torch, dev, B, nf, nsteps, rank, ref_fraction=0.5):
     """Truth stream shared by all filters, independent pixel noise per filter and step."""
     from slam_amd import synth
@@ -487,11 +498,17 @@ def main():
         # 2 n m^2, W = P H^T 12 n m and the lower half of S = H W + R 6 m (m + 1) with the six-entry rows of H
         solver_flops = B * (m ** 3 / 3.0 + 2.0 * n * m * m + 12.0 * n * m + 6.0 * m * (m + 1))
         achieved = solver_flops / (solver_ms * 1e-3) / 1e12
-        pmc = {}
-        side = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        # HBM bytes per launch from the PMC counters (scripts/pmc_traffic.sh): collected in passes of their own on this
+        # workload and kept with a hash of the kernel sources they belong to; reported only while that hash still matches
+        pmc, pmc_state = {}, "none collected for this workload"
+        side = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
         if os.path.exists(side) and B == 4096 and nf == 32:      # the counters were collected on this workload
             try:
-                pmc = json.load(open(side))["kernels"]
+                rec = json.load(open(side))
+                if rec.get("kernel_source_sha256") == kernel_source_sha256():
+                    pmc, pmc_state = rec["kernels"], "profiles/r03_pmc_traffic.json (rocprofv3 --pmc, FETCH_SIZE doubled)"
+                else:
+                    pmc_state = "stale: the kernel sources changed after profiles/r03_pmc_traffic.json was collected"
             except Exception:
                 pmc = {}
         def pmc_bytes(name):
@@ -544,7 +561,7 @@ def main():
                          "executed_tile_flops_frac": solver_exec_flops / (solver_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
                          "fp64_mfma_frac_all_mfma_kernels": (solver_flops + cov_flops) / (mfma_ms * 1e-3) / 1e12
                                                             / FP64_MATRIX_PEAK_TFLOPS,
-                         "traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc, FETCH_SIZE doubled)"},
+                         "traffic_source": pmc_state},
             "other_kernels": kernels,
             # the dense formulation's work (8n^3 + 6n^2 m + 4nm^2 + m^3/3 + 2nm per update) priced at the measured rate:
             # what an all-GEMM pipeline would have to sustain to match `value`; the sparse Jacobian products skip

@@ -2,7 +2,19 @@
 
 FETCH_SIZE on gfx950 counts 64 B per 128-B read request of a wide coalesced stream, so the read side is
 reported both raw and doubled; WRITE_SIZE is taken as is."""
-import csv, glob, json, sys, collections
+import csv, glob, hashlib, json, os, sys, collections
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_sha256():
+    """Hash of the kernel sources the counters belong to (bench.py only reports the traffic while it still matches)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "slam_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 
 
 def load(d, counter):
@@ -31,7 +43,8 @@ def main():
                   "hbm_bytes_per_launch_raw": (f / max(fn, 1) + w / max(wn, 1)) * 1024,
                   "hbm_bytes_per_launch_fetch_doubled": (2 * f / max(fn, 1) + w / max(wn, 1)) * 1024}
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 3 --warmup 1",
-               "kernels": res}, open(out, "w"), indent=1)
+               "kernel_source_sha256": kernel_source_sha256(), "kernel_names": sorted(res), "kernels": res},
+              open(out, "w"), indent=1)
     for k, v in res.items():
         print("%-60s n=%4d  fetch %10.0f KB  write %10.0f KB" % (k[:60], v["launches"], v["fetch_kb_per_launch_raw"], v["write_kb_per_launch"]))
 
