@@ -440,7 +440,7 @@ int run_predict(slamk_handle* h, const Range& rg, const double* qbw, const doubl
     const int nt = (nl + 2) / 3;
     if (nt <= 128) {           // moderate sizes: bands of row triples staged through LDS, all global accesses contiguous
         const int nthr = 256, hband = nthr / nt;     // 128 and 512 threads measured slower (0.32, 0.30 vs 0.28 ms)
-        hipLaunchKernelGGL(predict_cov_band_kernel, dim3((nt + hband - 1) / hband, B), dim3(nthr),
+        hipLaunchKernelGGL(predict_cov_band_kernel, dim3(((nt + hband - 1) / hband) * 8 * ((B + 7) / 8)), dim3(nthr),
                            predict_band_lds_bytes(nl, hband), st, rg.fv, rg.fv.P, rg.T, nl, hband);
     } else
         hipLaunchKernelGGL(predict_cov_kernel, dim3((nt * nt + 255) / 256, B), dim3(256), 0, st, rg.fv, rg.fv.P, rg.T, nl);

@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256) predict_cov_kernel(FilterView fv, const d
 // the operand rows of the band (the velocity rows 3..5 and each triple's own group) and the compact rows of F go
 // through LDS with coalesced 16-byte loads, the finished band leaves through LDS the same way, so every global
 // access is a contiguous run; the arithmetic (and its order) is that of predict_cov_kernel.
-// grid (ceil(nt / hband), B), up to 512 threads; dynamic LDS predict_band_lds_bytes(nl, hband).
+// grid (ceil(nt / hband) * 8 * ceil(B / 8)), up to 512 threads; dynamic LDS predict_band_lds_bytes(nl, hband).
 __host__ __device__ inline size_t predict_band_lds_bytes(int nl, int hband)
 {
     const int nt = (nl + 2) / 3;
@@ -292,9 +292,17 @@ __global__ void __launch_bounds__(512) predict_cov_band_kernel(FilterView fv, co
                                                                 double* __restrict__ Pout, int nl, int hband)
 {
     extern __shared__ double plds[];
-    const int b = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;
     const int nt = (nl + 2) / 3;
-    const int t0 = blockIdx.x * hband;
+    // Workgroups are dealt round-robin to the 8 XCDs, each with an L2 of its own: the bands of one filter (which all
+    // read its velocity rows and its compact rows of F) are given workgroup ids 8 apart, so that they run on one XCD
+    // right after one another and those re-reads stay in its L2.  (A matter of speed only: nothing depends on where a
+    // workgroup runs.)
+    const int nb = (nt + hband - 1) / hband;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int b = (seq / nb) * 8 + xcd, band = seq - (seq / nb) * nb;
+    if (b >= fv.B) return;
+    const int t0 = band * hband;
     const int hb = min(hband, nt - t0);
     const long long cb = (long long)b * fv.ldn;
     const int ldn = fv.ldn;
@@ -306,10 +314,15 @@ __global__ void __launch_bounds__(512) predict_cov_band_kernel(FilterView fv, co
     int* cgs = reinterpret_cast<int*>(cfg + 9 * nt);      // [nt]
 
     // stage: operand rows (16-byte pieces), compact rows of F, group starts
+    // (the group of a triple is the triple itself, except for the velocity rows, whose group is the bias triple --
+    // motion_row: worked out here from the feature count, so that the loads of P do not wait for a load of fgs)
     const int half = nl >> 1, pieces = (hb + 1) * 3 * half;
+    const int nfb = fv.nf[b], nst = 9 + 3 * nfb;
     for (int idx = tid; idx < pieces; idx += nthr) {
         const int row = idx / half, c2 = idx - row * half;
-        const int src = row < 3 ? 3 + row : fv.fgs[cb + 3 * (t0 + (row - 3) / 3)] + (row - 3) % 3;
+        const int tr = t0 + (row - 3) / 3;
+        const int g0 = 3 * tr >= nst ? 0 : (tr == 1 ? 6 + 3 * nfb : 3 * tr);
+        const int src = row < 3 ? 3 + row : g0 + (row - 3) % 3;
         reinterpret_cast<double2*>(img + (size_t)row * nl)[c2] =
             reinterpret_cast<const double2*>(Pb + (long long)src * ldn)[c2];
     }
