@@ -104,6 +104,67 @@ def test_position_override_between_frame_and_fused_step():
         fb.close()
 
 
+@pytest.mark.parametrize("form", [0, 2])
+def test_override_with_only_some_filters_begun_by_a_frame(form):
+    """Three filters; only filter 1 gets slamk_frame (which takes old_pos = X), then a position override, then the fused
+    step for all: filter 1 must keep the old_pos of its frame (main.cpp:168 before :180-185), the other two take theirs
+    at the step -- per filter, against three single-filter handles driven through the three-call path."""
+    import torch
+    nf, B = 7, 3
+    st = synth.gen_stream(seed=29, nf=nf, steps=5, churn=False, image_every=1)
+    inp = helpers.stream_inputs(st, 7)
+    dev = torch.device("cuda")
+    stream = torch.cuda.Stream(device=dev)
+    prm = ekf.default_params()
+    prm.update_form = form
+    fb = ekf.FilterBatch(max_features=nf, batch=B, params=prm)
+    refs = [ekf.FilterBatch(max_features=nf, batch=1, params=prm) for _ in range(B)]
+    for b in range(B):
+        fb.set_state(b, X=st.init_pos)
+        refs[b].set_state(0, X=st.init_pos)
+        refs[b].frame(0, inp[0][5], inp[0][1])
+    fb.frame(-1, inp[0][5], inp[0][1])
+    for k in range(1, 5):
+        u, quat, ang, acc, dt, matches = inp[k]
+        pos = st.steps[k].X_true + np.array([0.03, 0.01, -0.004])
+        one = lambda v: torch.tensor(np.tile(np.asarray(v, dtype=np.float64), (B, 1)), device=dev)
+        q, w, a = one(quat), one(ang), one(acc)
+        dtt = torch.full((B,), dt, device=dev, dtype=torch.float64)
+        ap = torch.zeros(B, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        fb.frame(1, matches, quat)               # filter 1 only: its frame begin runs here
+        fb.set_state(1, X=pos)                   # ... and its position is overridden afterwards
+        fb.set_frame_values(0, *_frame_vals(matches))
+        fb.set_frame_values(2, *_frame_vals(matches))
+        fb.step_dev(q.data_ptr(), w.data_ptr(), a.data_ptr(), dtt.data_ptr(), None, None, None, ap.data_ptr(),
+                    stream.cuda_stream)
+        fb.sync(stream.cuda_stream)
+        for b in range(B):
+            if b == 1:
+                refs[b].frame(0, matches, quat)
+                refs[b].set_state(0, X=pos)
+            else:                                # no frame call: same features, new observations, old_pos taken at the step
+                refs[b].set_frame_values(0, *_frame_vals(matches))
+                refs[b].frame_begin_dev(0)
+                refs[b].sync(0)
+            refs[b].predict(quat, ang, acc, [dt])
+            ap1 = refs[b].update(quat)[0]
+            assert int(ap[b].item()) == ap1
+            assert helpers.rel_err(fb.get_cov(b), refs[b].get_cov(0)) < 1e-13, (k, b)
+            assert helpers.rel_err(fb.state_vector(b), refs[b].state_vector(0)) < 1e-13, (k, b)
+    # the override really mattered: filter 1 differs from its neighbours
+    assert helpers.rel_err(fb.state_vector(1), fb.state_vector(0)) > 1e-6
+    fb.close()
+    for r in refs:
+        r.close()
+
+
+def _frame_vals(matches):
+    src = np.array([[m[1], m[2]] for m in matches], dtype=np.float64)
+    refl = np.array([[m[3], m[4]] for m in matches], dtype=np.float64)
+    return src, refl
+
+
 def test_debug_switch_invalidates_captured_graphs():
     """A graph captured without the dense-Jacobian kernels must not be replayed after slamk_set_debug(h, 1)."""
     import torch
