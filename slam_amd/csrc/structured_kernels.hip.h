@@ -317,12 +317,14 @@ __global__ void __launch_bounds__(512) predict_cov_band_kernel(FilterView fv, co
     // (the group of a triple is the triple itself, except for the velocity rows, whose group is the bias triple --
     // motion_row: worked out here from the feature count, so that the loads of P do not wait for a load of fgs)
     const int half = nl >> 1, pieces = (hb + 1) * 3 * half;
-    const int nfb = fv.nf[b], nst = 9 + 3 * nfb;
+    // (only the band that holds the velocity triple needs the feature count; rows past the last state are zero like
+    // their coefficients, so a padding triple may read its own rows)
+    const int bias0 = band == 0 ? 6 + 3 * fv.nf[b] : 0;
     for (int idx = tid; idx < pieces; idx += nthr) {
         const int row = idx / half, c2 = idx - row * half;
         const int tr = t0 + (row - 3) / 3;
-        const int g0 = 3 * tr >= nst ? 0 : (tr == 1 ? 6 + 3 * nfb : 3 * tr);
-        const int src = row < 3 ? 3 + row : g0 + (row - 3) % 3;
+        const int g0 = tr == 1 ? bias0 : 3 * tr;
+        const int src = row < 3 ? 3 + row : min(g0 + (row - 3) % 3, nl - 1);
         reinterpret_cast<double2*>(img + (size_t)row * nl)[c2] =
             reinterpret_cast<const double2*>(Pb + (long long)src * ldn)[c2];
     }
