@@ -11,6 +11,7 @@ __device__ unsigned long long g_stamps[8][32];
 #endif
 #include "../slam_amd/csrc/feature_kernels.hip.h"
 #include "../slam_amd/csrc/joseph_kernel.hip.h"
+#include "../slam_amd/csrc/joseph_quad.hip.h"
 using namespace slamk;
 template <typename T> T* dev(const std::vector<T>& h, int B)
 {
@@ -24,6 +25,7 @@ int main()
     std::vector<double> P((size_t)ldn * ldn), K((size_t)ldn * ldm), ha(ldm * 3), hb(ldm * 3), rd(ldm, 1.0);
     std::vector<int> rowoff(F), isref(F), nfv(1, nf), mv(1, 161), hcs(ldm, -1);
     for (auto& x : P) x = (double)rand() / RAND_MAX;
+    for (int i = 0; i < ldn; ++i) for (int j = 0; j < i; ++j) P[(size_t)j * ldn + i] = P[(size_t)i * ldn + j];   // symmetric
     for (auto& x : K) x = ((double)rand() / RAND_MAX - 0.5) * 0.01;
     for (auto& x : ha) x = (double)rand() / RAND_MAX;
     for (auto& x : hb) x = (double)rand() / RAND_MAX;
@@ -44,6 +46,50 @@ int main()
     std::vector<double> ev(ldm); for (auto& x : ev) x = (double)rand() / RAND_MAX - 0.5;
     fv.e = dev(ev, B);
     double* dxd; hipMalloc(&dxd, (size_t)B * ldn * 8);
+#ifdef QUAD
+    const size_t lq = (size_t)(NT * NT + 3 * NT + 10) * 256 * 8;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(joseph_quad_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(joseph_quad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq);
+    {   // against joseph_kernel on the same input
+        const size_t l0 = (size_t)(NT * NT + 2 * NT + 2) * 256 * 8;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(joseph_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l0);
+        for (int form = 0; form < 2; ++form) {
+            std::vector<double> r0(P.size()), r1(P.size()), d0(ldn), d1(ldn);
+            hipMemcpy(fv.P, P.data(), P.size() * 8, hipMemcpyHostToDevice);
+            joseph_kernel<NT><<<1, 512, l0>>>(fv, Kd, ldm, (long long)ldn * ldm, ml, form, dxd, 0, nullptr);
+            hipMemcpy(r0.data(), fv.P, P.size() * 8, hipMemcpyDeviceToHost);
+            hipMemcpy(d0.data(), dxd, ldn * 8, hipMemcpyDeviceToHost);
+            hipMemcpy(fv.P, P.data(), P.size() * 8, hipMemcpyHostToDevice);
+            if (form) joseph_quad_kernel<true><<<1, 256, lq>>>(fv, Kd, ldm, (long long)ldn * ldm, ml, dxd, 0, nullptr);
+            else joseph_quad_kernel<false><<<1, 256, lq>>>(fv, Kd, ldm, (long long)ldn * ldm, ml, dxd, 0, nullptr);
+            hipMemcpy(r1.data(), fv.P, P.size() * 8, hipMemcpyDeviceToHost);
+            hipMemcpy(d1.data(), dxd, ldn * 8, hipMemcpyDeviceToHost);
+            double worst = 0, wd = 0, big = 0;
+            for (size_t i = 0; i < r0.size(); ++i) { worst = fmax(worst, fabs(r0[i] - r1[i])); big = fmax(big, fabs(r0[i])); }
+            for (int i = 0; i < ldn; ++i) wd = fmax(wd, fabs(d0[i] - d1[i]));
+            printf("form %d: max |P_old - P_quad| = %.3e (max |P| %.3e), max |dx diff| = %.3e (%s)\n", form, worst, big, wd, hipGetErrorString(hipGetLastError()));
+        }
+        hipMemcpy(fv.P, P.data(), P.size() * 8, hipMemcpyHostToDevice);
+    }
+    hipEvent_t q0, q1; hipEventCreate(&q0); hipEventCreate(&q1);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(q0);
+        joseph_quad_kernel<false><<<B, 256, lq>>>(fv, Kd, ldm, (long long)ldn * ldm, ml, dxd, 0, nullptr);
+        hipEventRecord(q1); hipEventSynchronize(q1);
+        float ms; hipEventElapsedTime(&ms, q0, q1);
+        printf("%s: %.3f ms (%s)\n", VARIANT, ms, hipGetErrorString(hipGetLastError()));
+    }
+    {
+        unsigned long long hs[8][32];
+        hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_stamps), sizeof hs);
+        for (int w = 0; w < 4; ++w) {
+            printf("wave %d:", w);
+            for (int i = 1; i < 32; ++i) if (hs[w][i]) printf(" [%d]%lld", i, (long long)(hs[w][i] - hs[w][0]));
+            printf("\n");
+        }
+    }
+    return 0;
+#endif
 #ifdef MERGED
     auto kern = joseph_merged_kernel<NT>;
     const size_t lds = (size_t)(NT * NT + 2 * NT + 10) * 256 * 8;

@@ -437,18 +437,21 @@ __global__ void __launch_bounds__(512, (NT <= 2 ? 4 : 2)) joseph_merged_kernel(F
 #pragma unroll
         for (int c = 0; c < 3; ++c) hal[c] = fv.ha[(rb + ia) * 3 + c];
     }
-    const double* ksrc = Kb + (long long)(16 * wave + lk) * ldk + li;     // element (lk + 4 r, li) of tile `wave`
-    const long long r4 = (long long)4 * ldk;
+    // No branch around a load of K or P from here on: the wait for a chunk counts the loads requested after it, and
+    // the compiler can only count them along straight code (a wavefront without a tile reads the last tile and does
+    // not store it; past the last chunk the last one is read again).
     const bool loader = wave < NT;
-    double pre[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    if (loader) {
+    const double* ksrc = Kb + (long long)(16 * (loader ? wave : NT - 1) + lk) * ldk + li;     // element (lk + 4 r, li) of the tile
+    const long long r4 = (long long)4 * ldk;
+    double pre[2][4];                                   // chunk k waits in set k & 1
+    auto request_chunk = [&](int k, auto set_) {
+        constexpr int S = decltype(set_)::value;
+        const int kk = max(min(k, nchunk - 1), 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pre[0][r] = ksrc[r * r4];
-        if (nchunk > 1) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pre[1][r] = ksrc[r * r4 + 16];
-        }
-    }
+        for (int r = 0; r < 4; ++r) pre[S][r] = ksrc[r * r4 + 16 * kk];
+    };
+    request_chunk(0, std::integral_constant<int, 0>{});
+    request_chunk(1, std::integral_constant<int, 1>{});
     // compact rows of H for the chunk loop (mlc <= 208 < 512: one row per thread), requested here, stored below.
     // The altitude row is taken ahead of the loop (one thread per row of A, below), rows past it are padding.
     const bool trow = tid < mlc, tlive = tid < ia;
@@ -466,11 +469,10 @@ __global__ void __launch_bounds__(512, (NT <= 2 ? 4 : 2)) joseph_merged_kernel(F
     constexpr int PT = (NT * NT + 7) / 8;
     double pre_p[PT][4];
     auto request_p = [&](int u) {
-        const int t = wave + 8 * u;
+        const int t = min(wave + 8 * u, NT * NT - 1);
         const int I = t / NT, Jt = t - I * NT;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            pre_p[u][r] = (t < NT * NT) ? Pb[(long long)(16 * I + lk + 4 * r) * ldn + 16 * Jt + li] : 0.0;
+        for (int r = 0; r < 4; ++r) pre_p[u][r] = Pb[(long long)(16 * I + lk + 4 * r) * ldn + 16 * Jt + li];
     };
     for (int t = tid; t < NT * NT * 256; t += 512) lds[t] = 0.0;
     if (tid < 16 * NT) {
@@ -502,19 +504,15 @@ __global__ void __launch_bounds__(512, (NT <= 2 ? 4 : 2)) joseph_merged_kernel(F
 #pragma unroll
     for (int t = 0; t < NT; ++t) o[t] = (v4d){0.0, 0.0, 0.0, 0.0};
     v4d g2 = (v4d){0.0, 0.0, 0.0, 0.0};                  // rows lk + 4 r of the block: columns 0..2 of K H, column 3: K e
-    auto chunk = [&](int c) {
-        double* kc = kst + (c & 1) * NT * 256;
+    auto chunk = [&](int c, auto par_) {
+        constexpr int X = decltype(par_)::value;         // parity of c
+        double* kc = kst + X * NT * 256;
         if (loader) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) kc[wave * 256 + tsw(lk + 4 * r, li)] = pre[0][r];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pre[0][r] = pre[1][r];
+            for (int r = 0; r < 4; ++r) kc[wave * 256 + tsw(lk + 4 * r, li)] = pre[X][r];
         }
         __syncthreads();
-        if (loader && c + 2 < nchunk) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pre[1][r] = ksrc[r * r4 + 16 * (c + 2)];
-        }
+        request_chunk(c + 2, par_);
     };
     const int ntl = __builtin_amdgcn_readfirstlane(blk < NT ? NT - blk : 0);   // tiles of column J (scalar: uniform branches)
     double* ablk = lds + (NT - ntl) * NT * 256;                                // row block J of A
@@ -572,12 +570,30 @@ __global__ void __launch_bounds__(512, (NT <= 2 ? 4 : 2)) joseph_merged_kernel(F
             for (int r = 0; r < 4; ++r) ap[tsw(lk + 4 * r, colA & 15)] -= g1[r];
         }
     };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    if (nchunk >= PT) {                                      // the first chunks also carry the requests for the P tiles
 #pragma unroll
-    for (int u = 0; u < PT; ++u) {                           // the first chunks also carry the requests for the P tiles
-        if (u < nchunk) { chunk(u); request_p(u); chunk_work(u); }
-        else request_p(u);
+        for (int u = 0; u < PT; ++u) {
+            if (u & 1) chunk(u, I1{}); else chunk(u, I0{});
+            request_p(u);
+            chunk_work(u);
+        }
+        int c = PT;
+        if (PT & 1) {
+            for (; c + 1 < nchunk; c += 2) { chunk(c, I1{}); chunk_work(c); chunk(c + 1, I0{}); chunk_work(c + 1); }
+            if (c < nchunk) { chunk(c, I1{}); chunk_work(c); }
+        } else {
+            for (; c + 1 < nchunk; c += 2) { chunk(c, I0{}); chunk_work(c); chunk(c + 1, I1{}); chunk_work(c + 1); }
+            if (c < nchunk) { chunk(c, I0{}); chunk_work(c); }
+        }
+    } else {                                                 // few measurement rows: all tiles requested at once
+#pragma unroll
+        for (int u = 0; u < PT; ++u) request_p(u);
+        int c = 0;
+        for (; c + 1 < nchunk; c += 2) { chunk(c, I0{}); chunk_work(c); chunk(c + 1, I1{}); chunk_work(c + 1); }
+        if (c < nchunk) { chunk(c, I0{}); chunk_work(c); }
     }
-    for (int c = PT; c < nchunk; ++c) { chunk(c); chunk_work(c); }
     if (ntl > 0) {                                           // position columns and dx of this row block
         if (li < 3) {
 #pragma unroll

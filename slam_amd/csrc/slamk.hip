@@ -23,6 +23,7 @@
 #include "linalg_kernels.hip.h"
 #include "structured_kernels.hip.h"
 #include "joseph_kernel.hip.h"
+#include "joseph_quad.hip.h"
 #include "seq_update.hip.h"
 #include "preprocess_kernels.hip.h"
 #include "frame_kernels.hip.h"
@@ -722,6 +723,26 @@ int launch_joseph(slamk_handle* h, const Range& rg, int ml, int* applied, hipStr
     const size_t lds = (size_t)(NT * NT + (MERGED ? 2 * NT + 10 : NT + 2)) * 256 * sizeof(double);
     auto kern = [] { if constexpr (MERGED) return joseph_merged_kernel<NT>; else return joseph_kernel<NT>; }();
     if (MERGED && ml > 256) return fail(h, SLAMK_EINVAL, "fused covariance update: %d measurement rows for n <= %d", ml, 16 * NT);
+    if constexpr (NT == 7) {
+        // seven row blocks and 112..240 measurement columns in chunks: the variant with four wavefronts per filter
+        if (ml >= QUAD_MIN_COLS && ml <= QUAD_MAX_COLS && ml % 16 == 0) {
+            const size_t lq = (size_t)(NT * NT + 3 * NT + 10) * 256 * sizeof(double);
+            const bool simple = h->prm.update_form == 1;
+            const void* kq = simple ? reinterpret_cast<const void*>(joseph_quad_kernel<true>)
+                                    : reinterpret_cast<const void*>(joseph_quad_kernel<false>);
+            { int rc_ = ensure_dynamic_lds(h, kq, lq); if (rc_) return rc_; }
+            double* dxo = fuse_apply(rg.B) ? (double*)nullptr : rg.dx;
+            const int ap = fuse_apply(rg.B) ? 1 : 0;
+            if (simple)
+                hipLaunchKernelGGL(joseph_quad_kernel<true>, dim3(rg.B), dim3(256), lq, st, rg.fv, rg.K, h->ldm,
+                                   (long long)h->ldn * h->ldm, ml, dxo, ap, applied);
+            else
+                hipLaunchKernelGGL(joseph_quad_kernel<false>, dim3(rg.B), dim3(256), lq, st, rg.fv, rg.K, h->ldm,
+                                   (long long)h->ldn * h->ldm, ml, dxo, ap, applied);
+            HIPCHK(h, hipGetLastError());
+            return 0;
+        }
+    }
     { int rc_ = ensure_dynamic_lds(h, reinterpret_cast<const void*>(kern), lds); if (rc_) return rc_; }
     hipLaunchKernelGGL(kern, dim3(rg.B), dim3(512), lds, st, rg.fv, rg.K, h->ldm,
                        (long long)h->ldn * h->ldm, ml, h->prm.update_form, fuse_apply(rg.B) ? (double*)nullptr : rg.dx,
