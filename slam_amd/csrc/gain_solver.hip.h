@@ -44,14 +44,15 @@ __device__ __forceinline__ int tile_index(int i, int j) { return i * (i + 1) / 2
 
 // D = A * B + C on 16 x 16 tiles; A read from an LDS tile, rows = lanes (optionally the transposed
 // tile, optionally negated); B is an accumulator-shaped register tile.
+// A negated operand is the instruction's own negate bit (last argument of the builtin: 1 = A, 2 = B, 4 = C), never an
+// instruction of the vector ALU: on gfx950 those do not issue beside an fp64 matrix instruction of the same SIMD.
 template <bool TRANS, bool NEG>
 __device__ __forceinline__ v4d tile_mma_regB(const double* __restrict__ ta, v4d b, v4d c, int li, int lk)
 {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        double a = TRANS ? ta[tsw(4 * s + lk, li)] : ta[tsw(li, 4 * s + lk)];
-        if (NEG) a = -a;
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s], c, 0, 0, 0);
+        const double a = TRANS ? ta[tsw(4 * s + lk, li)] : ta[tsw(li, 4 * s + lk)];
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s], c, 0, 0, NEG ? 1 : 0);
     }
     return c;
 }
@@ -66,11 +67,10 @@ __device__ __forceinline__ v4d tile_mma_ldsBt(const double* __restrict__ ta, con
     const int o0 = li * 16 + ((4 * lk) ^ (li & 14)), o1 = li * 16 + ((4 * lk + 2) ^ (li & 14));
     const double2 a01 = *reinterpret_cast<const double2*>(ta + o0), a23 = *reinterpret_cast<const double2*>(ta + o1);
     const double2 b01 = *reinterpret_cast<const double2*>(tb + o0), b23 = *reinterpret_cast<const double2*>(tb + o1);
-    const double sg = NEG ? -1.0 : 1.0;
-    c = __builtin_amdgcn_mfma_f64_16x16x4f64(sg * a01.x, b01.x, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f64_16x16x4f64(sg * a01.y, b01.y, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f64_16x16x4f64(sg * a23.x, b23.x, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f64_16x16x4f64(sg * a23.y, b23.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, b01.x, c, 0, 0, NEG ? 1 : 0);
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, b01.y, c, 0, 0, NEG ? 1 : 0);
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, b23.x, c, 0, 0, NEG ? 1 : 0);
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, b23.y, c, 0, 0, NEG ? 1 : 0);
     return c;
 }
 
@@ -216,7 +216,7 @@ __device__ __forceinline__ void diag_tile_factor_invert_acc(v4d a, double* __res
             for (int q = 0; q < 4; ++q) Lg[(long long)li * ldl + 4 * kb + q] = x[q];
         }
         const double xo = pick4(x, lk);
-        if (kb < 3) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-xo, xo, a, 0, 0, 0);
+        if (kb < 3) a = __builtin_amdgcn_mfma_f64_16x16x4f64(xo, xo, a, 0, 0, 1);
         double iv[10], rr[4], xi[4];
         inv4(l, id, iv);
         rows_allgather(R[kb], rr);
@@ -226,7 +226,7 @@ __device__ __forceinline__ void diag_tile_factor_invert_acc(v4d a, double* __res
         xi[3] = fma(iv[9], rr[3], fma(iv[8], rr[2], fma(iv[7], rr[1], iv[6] * rr[0])));
         const double xs = pick4(xi, lk);
         out[kb] = xs;
-        if (kb < 3) R = __builtin_amdgcn_mfma_f64_16x16x4f64(-xo, xs, R, 0, 0, 0);
+        if (kb < 3) R = __builtin_amdgcn_mfma_f64_16x16x4f64(xo, xs, R, 0, 0, 1);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) t[tsw(lk + 4 * r, li)] = out[r];
@@ -288,13 +288,13 @@ __device__ __forceinline__ void tile_cholesky_forward(double* lds, v4d (&y)[MT],
 #pragma unroll
         for (int k = 0; k < MT; ++k)
             if (k < j) {
-                const double a0 = -an[0], a1 = -an[1], a2 = -an[2], a3 = -an[3];
+                const double a0 = an[0], a1 = an[1], a2 = an[2], a3 = an[3];
                 fetch(k + 1);                            // k + 1 == j: the diagonal tile
                 v4d& c = (k & 1) ? acc2 : acc;
-                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, y[k][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, y[k][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, y[k][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, y[k][3], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, y[k][0], c, 0, 0, 1);
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, y[k][1], c, 0, 0, 1);
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, y[k][2], c, 0, 0, 1);
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, y[k][3], c, 0, 0, 1);
             }
         acc += acc2;
         v4d out = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -643,14 +643,14 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
 #pragma unroll
             for (int k = 0; k < MT; ++k)
                 if (k >= k0 && k <= k1) {
-                    const double x0 = -a01.x, x1 = -a01.y, x2 = -a23.x, x3 = -a23.y;
+                    const double x0 = a01.x, x1 = a01.y, x2 = a23.x, x3 = a23.y;
                     const double z0 = b01.x, z1 = b01.y, z2 = b23.x, z3 = b23.y;
                     if (k < k1) fetch(k + 1);
                     v4d& d = ((k - k0) & 1) ? acc2 : acc;
-                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, z0, d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, z1, d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, z2, d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, z3, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, z0, d, 0, 0, 1);
+                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, z1, d, 0, 0, 1);
+                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, z2, d, 0, 0, 1);
+                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, z3, d, 0, 0, 1);
                 }
             acc += acc2;
 #pragma unroll
@@ -668,13 +668,13 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
 #pragma unroll
             for (int k = 0; k < MT; ++k)
                 if (k < j) {
-                    const double a0 = -an[0], a1 = -an[1], a2 = -an[2], a3 = -an[3];
+                    const double a0 = an[0], a1 = an[1], a2 = an[2], a3 = an[3];
                     fetch(k + 1);
                     v4d& c = (k & 1) ? acc2 : acc;
-                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, y[k][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, y[k][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, y[k][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, y[k][3], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, y[k][0], c, 0, 0, 1);
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, y[k][1], c, 0, 0, 1);
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, y[k][2], c, 0, 0, 1);
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, y[k][3], c, 0, 0, 1);
                 }
             acc += acc2;
             v4d out = (v4d){0.0, 0.0, 0.0, 0.0};

@@ -205,13 +205,13 @@ __device__ __forceinline__ void seq_update_filter(const FilterView& fv, int b, d
                 yb[u][1] = *reinterpret_cast<const double2*>(wp + J * 256 + o1);
             }
 #pragma unroll
-            for (int u = 0; u < SLOTS; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ya[u][0].x, yb[u][0].x, acc[u], 0, 0, 0);
+            for (int u = 0; u < SLOTS; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[u][0].x, yb[u][0].x, acc[u], 0, 0, 1);
 #pragma unroll
-            for (int u = 0; u < SLOTS; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ya[u][0].y, yb[u][0].y, acc[u], 0, 0, 0);
+            for (int u = 0; u < SLOTS; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[u][0].y, yb[u][0].y, acc[u], 0, 0, 1);
 #pragma unroll
-            for (int u = 0; u < SLOTS; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ya[u][1].x, yb[u][1].x, acc[u], 0, 0, 0);
+            for (int u = 0; u < SLOTS; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[u][1].x, yb[u][1].x, acc[u], 0, 0, 1);
 #pragma unroll
-            for (int u = 0; u < SLOTS; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ya[u][1].y, yb[u][1].y, acc[u], 0, 0, 0);
+            for (int u = 0; u < SLOTS; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[u][1].y, yb[u][1].y, acc[u], 0, 0, 1);
 #pragma unroll
             for (int u = 0; u < SLOTS; ++u) {
                 const int t = t0 + 8 * u;
