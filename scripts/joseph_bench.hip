@@ -47,6 +47,9 @@ int main()
     fv.e = dev(ev, B);
     double* dxd; hipMalloc(&dxd, (size_t)B * ldn * 8);
 #ifdef QUAD
+#ifndef QGRID
+#define QGRID B
+#endif
     const size_t lq = (size_t)(NT * NT + 3 * NT + 10) * 256 * 8;
     hipFuncSetAttribute(reinterpret_cast<const void*>(joseph_quad_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq);
     hipFuncSetAttribute(reinterpret_cast<const void*>(joseph_quad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq);
@@ -72,12 +75,17 @@ int main()
         hipMemcpy(fv.P, P.data(), P.size() * 8, hipMemcpyHostToDevice);
     }
     hipEvent_t q0, q1; hipEventCreate(&q0); hipEventCreate(&q1);
-    for (int rep = 0; rep < 3; ++rep) {
-        hipEventRecord(q0);
-        joseph_quad_kernel<false><<<B, 256, lq>>>(fv, Kd, ldm, (long long)ldn * ldm, ml, dxd, 0, nullptr);
-        hipEventRecord(q1); hipEventSynchronize(q1);
-        float ms; hipEventElapsedTime(&ms, q0, q1);
-        printf("%s: %.3f ms (%s)\n", VARIANT, ms, hipGetErrorString(hipGetLastError()));
+    {
+        float best = 1e9f, sum = 0.f;
+        const int reps = 12;
+        for (int rep = 0; rep < reps; ++rep) {
+            hipEventRecord(q0);
+            joseph_quad_kernel<false><<<QGRID, 256, lq>>>(fv, Kd, ldm, (long long)ldn * ldm, ml, dxd, 0, nullptr);
+            hipEventRecord(q1); hipEventSynchronize(q1);
+            float ms; hipEventElapsedTime(&ms, q0, q1);
+            if (rep >= 2) { best = ms < best ? ms : best; sum += ms; }
+        }
+        printf("%s: best %.3f ms, mean %.3f ms over %d (%s)\n", VARIANT, best, sum / (reps - 2), reps - 2, hipGetErrorString(hipGetLastError()));
     }
     {
         unsigned long long hs[8][32];

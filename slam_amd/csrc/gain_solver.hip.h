@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
     extern __shared__ double lds[];                     // SolverLds<MT, SPILL>::TILES tiles of 256 doubles
     using Lds = SolverLds<MT, SPILL>;
     const int b = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar: what depends on it runs on the scalar unit)
     const int li = lane & 15, lk = lane >> 4;
     const int ldm = fv.ldm, ldn = fv.ldn;
     double* Lb = L ? L + (long long)b * sM : nullptr;
@@ -887,7 +887,7 @@ __global__ void __launch_bounds__(512, 4) chol_inv_block_kernel(const double* __
 {
     extern __shared__ double lds[];                     // MT (MT + 1) / 2 tiles + one scratch tile
     const int b = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const long long o = (long long)b * sM + (long long)j0 * ld + j0;
     const double* Sb = S + (long long)b * sS;

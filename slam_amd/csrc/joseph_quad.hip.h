@@ -491,23 +491,38 @@ __global__ void __launch_bounds__(256) joseph_quad_kernel(FilterView fv, const d
     }
     JOSEPH_STAMP(6);
     // Every tile goes out twice: as it is (rows of 128 bytes), and mirrored; the mirror image is read back transposed
-    // from a staging tile (the chunk buffers are free) so that its stores are rows of 128 bytes as well.
+    // from a staging tile (the chunk buffers are free) so that its stores are rows of 128 bytes as well.  Buffer stores:
+    // the tile's offset in a scalar register, the lane's offset the same for both images.  On the two diagonal tiles
+    // (the first of each column) the lower triangle goes out as it is and mirrored strictly above the diagonal.
+    typedef int v2s_t __attribute__((ext_vector_type(2)));
+    auto buffer_st = [](double v, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+        v2s_t d;
+        d.x = __double2loint(v); d.y = __double2hiint(v);
+        __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, voff, soff, 0);
+    };
     double* sc = kst + wave * 256;
+    double* scw[4];
+    const double* scr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { scw[r] = sc + tsw(lk + 4 * r, li); scr[r] = sc + tsw(li, lk + 4 * r); }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int I = rowblk(t), J = sec(t) ? Jb : Ja;
+        const int so = (16 * I * ldn + 16 * J) * 8, som = (16 * J * ldn + 16 * I) * 8;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sc[tsw(lk + 4 * r, li)] = o[t][r];
+        for (int r = 0; r < 4; ++r) *scw[r] = o[t][r];
+        if (I != J) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * I + lk + 4 * r, col = 16 * J + li;
-            if (row >= col) Pb[(long long)row * ldn + col] = o[t][r];
-        }
+            for (int r = 0; r < 4; ++r) buffer_st(o[t][r], prsrc, pvo[r], so);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int a = li, bq = lk + 4 * r;             // element (a, bq) of the tile -> out[16 J + bq][16 I + a]
-            const double v = sc[tsw(a, bq)];
-            if (16 * I + a > 16 * J + bq) Pb[(long long)(16 * J + bq) * ldn + 16 * I + a] = v;
+            for (int r = 0; r < 4; ++r) buffer_st(*scr[r], prsrc, pvo[r], som);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (lk + 4 * r >= li) buffer_st(o[t][r], prsrc, pvo[r], so);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (li > lk + 4 * r) buffer_st(*scr[r], prsrc, pvo[r], som);
         }
     }
     JOSEPH_STAMP(7);
