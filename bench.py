@@ -521,12 +521,20 @@ def main():
         cov_flops = B * (3.0 * n ** 3 + 1.0 * n * n * m)      # A P 2n^3, lower (A P) A^T n^3, lower K R K^T n^2 m
         pred_ms = prof["struct_predict"][0] / K
         pred_bytes = 2.0 * B * nl * nl * 8
+        # which kernel the library takes (launch_joseph, slam_amd/csrc/slamk.hip): seven row blocks and 112..240
+        # measurement columns in chunks -> four wavefronts per filter; up to n = 112 -> one pass over K; else two
+        mlc = m - 1 if (m - 1) % 16 == 0 else (m + 15) // 16 * 16
+        if nl == 112 and 112 <= mlc <= 240:
+            cov_name, cov_what = "joseph_quad_kernel", "joseph_quad_kernel (four wavefronts per filter: K R K^T, A = I - K H and dx = K e on one pass over K; A P; (A P) A^T)"
+        elif nl <= 112:
+            cov_name, cov_what = "joseph_merged_kernel", "joseph_merged_kernel (K R K^T, A = I - K H and dx = K e on one pass over K; A P; (A P) A^T)"
+        else:
+            cov_name, cov_what = "joseph_kernel", "joseph_kernel (A = I - K H, A P, (A P) A^T + K R K^T)"
         kernels = [
-            {"kernel": "joseph_merged_kernel (K R K^T, A = I - K H and dx = K e on one pass over K; A P; (A P) A^T)"
-                       if nl <= 112 else "joseph_kernel (A = I - K H, A P, (A P) A^T + K R K^T)", "bound": "mfma", "ms": cov_ms,
+            {"kernel": cov_what, "bound": "mfma", "ms": cov_ms,
              "achieved": cov_flops / (cov_ms * 1e-3) / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
              "frac": cov_flops / (cov_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
-             "traffic": pmc_bytes("joseph_merged_kernel" if nl <= 112 else "joseph_kernel"),
+             "traffic": pmc_bytes(cov_name),
              "executed_tile_flops_frac": cov_exec_flops / (cov_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS},
             {"kernel": "predict_cov_kernel (P = F P F^T + Q, F in compact row form)", "bound": "hbm", "ms": pred_ms,
              "achieved": pred_bytes / (pred_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

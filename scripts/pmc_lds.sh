@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for k in joseph solver; do
   rm -rf $R/gpurun_out/pmc_$k
-  timeout -s KILL 60 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$k -- $R/scripts/${k}_bench_FULL > $R/gpurun_out/pmc_$k.log 2>&1 || exit 1
+  timeout -s KILL 60 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$k -- $R/scripts/${k}_bench_FULL > $R/gpurun_out/pmc_$k.log 2>&1 || exit 1
   python3 - <<PY
 import csv,glob,collections
 acc=collections.defaultdict(lambda: collections.defaultdict(float))
