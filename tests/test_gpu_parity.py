@@ -95,13 +95,17 @@ def test_single_filter_stream_parity(nf, form):
                                                   (13, 0.5, 0), (29, 0.5, 0), (1, 1.0, 0), (34, 0.5, 0), (36, 0.5, 0),
                                                   (39, 0.5, 0), (39, 1.0, 0), (39, 1.0, 1), (32, 1.0, 0),
                                                   (2, 0.5, 2), (38, 0.0, 2), (36, 1.0, 2), (13, 0.5, 2), (1, 1.0, 2),
-                                                  (50, 0.5, 2), (45, 1.0, 2)])
+                                                  (50, 0.5, 2), (45, 1.0, 2),
+                                                  (30, 0.0, 0), (30, 1.0, 0), (34, 1.0, 0), (34, 1.0, 1), (32, 0.0, 0),
+                                                  (32, 0.0, 1), (31, 0.3, 0), (33, 0.7, 0)])
 def test_fused_path_tile_count_edges(nf, ref_fraction, form):
     """Smallest filter, eight 16-row blocks of the state (n = 123), all-reflection rows (m = 157), and a filter
     whose S exceeds LDS (m = 171 .. 235: the solver keeps the finished tiles of the factor in an image in global
     memory, 11 to 15 tile columns) while its P still fits the fused covariance update (n <= 126); state
     dimensions that fill their tiles exactly (n = 48, 96: no padding rows); a single reflective feature.  Form 2 (the
-    block-sequential update) at the same edges and at its own: n = 159 (ten row blocks, its limit) and m = 271."""
+    block-sequential update) at the same edges and at its own: n = 159 (ten row blocks, its limit) and m = 271.
+    The last line: seven row blocks (n = 99 .. 111), where the covariance update runs with four wavefronts per filter:
+    8 to 13 chunks of measurement columns, the altitude row inside the chunks and as the border (m = 129), both forms."""
     st = synth.gen_stream(seed=70 + nf, nf=nf, steps=31, churn=False, ref_fraction=ref_fraction)
     so, _ = helpers.run_oracle(st)
     p = ekf.default_params()
