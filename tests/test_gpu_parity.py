@@ -451,12 +451,15 @@ def test_graph_mode_replays_the_same_iteration():
         fb.close()
 
 
-def test_mixed_feature_counts_in_one_batch():
-    """Filters with different nf share one launch (dimensions are padded to the batch maximum)."""
-    sts = [synth.gen_stream(seed=30 + i, nf=nf, steps=7, churn=False) for i, nf in enumerate((4, 11, 7))]
+@pytest.mark.parametrize("nfs", [(4, 11, 7), (32, 5, 20, 33)])
+def test_mixed_feature_counts_in_one_batch(nfs):
+    """Filters with different nf share one launch (dimensions are padded to the batch maximum); the second set is
+    launched with seven row blocks (the covariance update with four wavefronts per filter) for filters of one to
+    seven."""
+    sts = [synth.gen_stream(seed=30 + i, nf=nf, steps=7, churn=False) for i, nf in enumerate(nfs)]
     sts.append(synth.gen_stream(seed=34, nf=3, steps=7, churn=False, drop_at=3, drop_count=3))   # empties at the 2nd frame
     B = len(sts)
-    fb = ekf.FilterBatch(max_features=11, batch=B)
+    fb = ekf.FilterBatch(max_features=max(nfs), batch=B)
     inps = [helpers.stream_inputs(st, 5) for st in sts]
     so = [helpers.run_oracle(st, noise_seed=5)[0] for st in sts]
     for b in range(B):
