@@ -479,14 +479,43 @@ def main():
     # RCCL all-gathers inside the library (every rank takes part; rank 0 reports)
     sharded_nf = args.sharded_nf if args.sharded_nf >= 0 else (0 if args.no_extra else 2000)
     sharded = None
+    sharded_failed = False
     if dist is not None and sharded_nf > 0:
         for s_ in steps:
             s_.clear()                   # the batched workload's inputs are no longer needed: free their HBM
         torch.cuda.empty_cache()
-        sharded = large_map_sharded(torch, dev, dist, rank, world, nf=sharded_nf)
-        if rank == 0 and not args.no_extra:
-            sharded["one_gpu_unsharded_ms_per_update"] = large_map(torch, dev, nf=sharded_nf)["ms_per_update"]
-        dist.barrier()
+        # This leg is a side measurement with collectives of its own: whatever happens in it (an exception on one rank,
+        # a collective that never completes) must not cost the line of the batched workload measured above.  It runs
+        # in a thread with a time limit; a rank whose leg failed or ran out of time skips every later collective, rank 0
+        # prints its line, and the process ends without waiting for the others.
+        import threading
+        box = {}
+
+        def leg():
+            try:
+                torch.cuda.set_device(dev)
+                r = large_map_sharded(torch, dev, dist, rank, world, nf=sharded_nf)
+                dist.barrier()
+                box["result"] = r
+            except BaseException as e:                                   # noqa: BLE001 (reported in the line)
+                box["error"] = "%s: %s" % (type(e).__name__, e)
+        th = threading.Thread(target=leg, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("SLAM_BENCH_SHARDED_TIMEOUT_S", "300")))
+        if th.is_alive():
+            box["error"] = "no result within the time limit"
+        if "error" in box:
+            sharded_failed = True
+            sharded = {"workload": "single filter, %d features, covariance sharded by row blocks over %d GPUs" % (sharded_nf, world),
+                       "error": box["error"]}
+        else:
+            sharded = box["result"]
+            if rank == 0 and not args.no_extra:
+                try:
+                    sharded["one_gpu_unsharded_ms_per_update"] = large_map(torch, dev, nf=sharded_nf)["ms_per_update"]
+                except Exception as e:                                   # noqa: BLE001
+                    sharded["one_gpu_unsharded_ms_per_update"] = None
+                    sharded["one_gpu_unsharded_error"] = "%s: %s" % (type(e).__name__, e)
 
     if rank == 0:
         # Dominant kernel: gain_solver_kernel (W = P H^T, S = H W + R, tile Cholesky, K = W S^-1), one launch per step, timed
@@ -608,6 +637,9 @@ def main():
                                "points": [sweep_point(torch, dev, nf_, B_, form=2) for nf_, B_ in
                                           ((8, 4096), (20, 4096), (32, 4096), (36, 1024), (40, 1024), (48, 1024))]}}
         print(json.dumps(out), flush=True)
+    if sharded_failed:
+        sys.stdout.flush()
+        os._exit(0)                      # (other ranks may sit in a collective that will not complete)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

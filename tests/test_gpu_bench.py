@@ -53,3 +53,19 @@ def test_bench_rank_sharded_two_ranks_over_gloo():
     assert d["config"]["batch_per_gpu"] == 96 and "x 2 GPUs" in d["config"]["workload"]
     # whole-job value: both ranks' filters over the slowest rank's time
     assert abs(d["value"] - 2 * 96 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
+
+
+def test_bench_line_survives_a_failed_large_map_leg():
+    """The row-block sharded large-map leg of a multi-GPU run is a side measurement with collectives of its own: when it
+    does not come back (here: a time limit no run can meet), rank 0 still prints the line of the batched workload, the
+    leg's entry carries the reason, and the job ends with status 0."""
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ, SLAM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", SLAM_BENCH_SHARDED_TIMEOUT_S="0.001")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3",
+                        "--warmup", "1", "--batch-per-gpu", "96", "--no-cpu", "--no-extra", "--sharded-nf", "60"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["outputs_sane"] and d["value"] > 0
+    assert "error" in d["also"]["large_map_sharded"]
