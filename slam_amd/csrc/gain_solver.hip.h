@@ -273,11 +273,11 @@ __device__ __forceinline__ void tile_cholesky_forward(double* lds, v4d (&y)[MT],
     };
     // Y^T_j = inv(L_jj) (B^T_j - sum_{k<j} L_jk Y^T_k): a finished tile, lane = column, register = row group,
     // IS the B operand of the next MFMA.
-    // The sum runs in two interleaved chains (even and odd k): consecutive MFMAs of one chain wait for each other.
+    // The sum is ONE chain of matrix instructions on one accumulator: dependent fp64 matrix instructions run back to
+    // back on gfx950 (64 cycles each), a second chain would only cost the additions that join them.
     // The operand fragment of the next tile is requested before the products of the current one are issued, so
     // that its LDS latency passes behind them.
     auto forward_step = [&](int j, v4d acc) {
-        v4d acc2 = (v4d){0.0, 0.0, 0.0, 0.0};
         double an[4];
         auto fetch = [&](int k) {                        // row fragment of L_jk (k < j) or of inv(L_jj) (k == j)
             const double* ta = lds + tile_index(j, k) * 256;
@@ -290,13 +290,12 @@ __device__ __forceinline__ void tile_cholesky_forward(double* lds, v4d (&y)[MT],
             if (k < j) {
                 const double a0 = an[0], a1 = an[1], a2 = an[2], a3 = an[3];
                 fetch(k + 1);                            // k + 1 == j: the diagonal tile
-                v4d& c = (k & 1) ? acc2 : acc;
+                v4d& c = acc;
                 c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, y[k][0], c, 0, 0, 1);
                 c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, y[k][1], c, 0, 0, 1);
                 c = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, y[k][2], c, 0, 0, 1);
                 c = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, y[k][3], c, 0, 0, 1);
             }
-        acc += acc2;
         v4d out = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int s = 0; s < 4; ++s) out = __builtin_amdgcn_mfma_f64_16x16x4f64(an[s], acc[s], out, 0, 0, 0);
@@ -622,7 +621,7 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
                 for (int r = 0; r < 4; ++r) tg[tsw(lk + 4 * r, li)] = acc[r];
             }
         };
-        // S_ic -= sum_{k = k0}^{k1} L_ik L_ck^T: two interleaved accumulator chains, k ascending in each; the operands
+        // S_ic -= sum_{k = k0}^{k1} L_ik L_ck^T: one accumulator chain, k ascending; the operands
         // of the next product are requested before the matrix instructions of the current one are issued
         auto update_tile = [&](int i, int c, int k0, int k1, int thr) {
             double* tic = tslot(i, c);
@@ -637,7 +636,7 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
                 b23 = *reinterpret_cast<const double2*>(rc + o1);
             };
             fetch(k0);
-            v4d acc, acc2 = (v4d){0.0, 0.0, 0.0, 0.0};
+            v4d acc;
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r] = tic[tsw(lk + 4 * r, li)];
 #pragma unroll
@@ -646,18 +645,16 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
                     const double x0 = a01.x, x1 = a01.y, x2 = a23.x, x3 = a23.y;
                     const double z0 = b01.x, z1 = b01.y, z2 = b23.x, z3 = b23.y;
                     if (k < k1) fetch(k + 1);
-                    v4d& d = ((k - k0) & 1) ? acc2 : acc;
+                    v4d& d = acc;
                     d = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, z0, d, 0, 0, 1);
                     d = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, z1, d, 0, 0, 1);
                     d = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, z2, d, 0, 0, 1);
                     d = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, z3, d, 0, 0, 1);
                 }
-            acc += acc2;
 #pragma unroll
             for (int r = 0; r < 4; ++r) tic[tsw(lk + 4 * r, li)] = acc[r];
         };
         auto forward_step = [&](int j, v4d acc, int thr) {   // as in tile_cholesky_forward
-            v4d acc2 = (v4d){0.0, 0.0, 0.0, 0.0};
             double an[4];
             auto fetch = [&](int k) {
                 const double* ta = tread(j, k, thr);
@@ -670,13 +667,12 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
                 if (k < j) {
                     const double a0 = an[0], a1 = an[1], a2 = an[2], a3 = an[3];
                     fetch(k + 1);
-                    v4d& c = (k & 1) ? acc2 : acc;
+                    v4d& c = acc;
                     c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, y[k][0], c, 0, 0, 1);
                     c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, y[k][1], c, 0, 0, 1);
                     c = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, y[k][2], c, 0, 0, 1);
                     c = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, y[k][3], c, 0, 0, 1);
                 }
-            acc += acc2;
             v4d out = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int s = 0; s < 4; ++s) out = __builtin_amdgcn_mfma_f64_16x16x4f64(an[s], acc[s], out, 0, 0, 0);
@@ -852,13 +848,9 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
     double mag = fabs(k_alt);                            // a pivot that was not positive has made K NaN or infinite
 #pragma unroll
     for (int j = MT - 1; j >= 0; --j) {
-        v4d acc = y[j], acc2 = (v4d){0.0, 0.0, 0.0, 0.0};      // two interleaved chains, as in the forward solve
+        v4d acc = y[j];
 #pragma unroll
-        for (int k = j + 1; k < MT; k += 2) {
-            acc = tile_mma_regB<true, true>(tread(k, j, THR_END), y[k], acc, li, lk);
-            if (k + 1 < MT) acc2 = tile_mma_regB<true, true>(tread(k + 1, j, THR_END), y[k + 1], acc2, li, lk);
-        }
-        acc += acc2;
+        for (int k = j + 1; k < MT; ++k) acc = tile_mma_regB<true, true>(tread(k, j, THR_END), y[k], acc, li, lk);
         y[j] = tile_mma_regB<true, false>(tread(j, j, THR_END), acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
 #pragma unroll
         for (int r = 0; r < 4; ++r) stg[tsw(li, lk + 4 * r)] = y[j][r];
