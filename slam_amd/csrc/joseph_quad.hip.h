@@ -476,7 +476,6 @@ __global__ void __launch_bounds__(256) joseph_quad_kernel(FilterView fv, const d
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const double2 a2 = *reinterpret_cast<const double2*>((h ? ap1[t] : ap0[t]) + kt * 256);
-                        constexpr int dummy = 0; (void)dummy;
                         const bool s2 = t >= NT - NSEC;
                         o[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, s2 ? afb[4 * kt + 2 * h] : afa[4 * kt + 2 * h], o[t], 0, 0, 0);
                         o[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, s2 ? afb[4 * kt + 2 * h + 1] : afa[4 * kt + 2 * h + 1], o[t], 0, 0, 0);
