@@ -400,14 +400,17 @@ __device__ __forceinline__ void store_offdiag_tiles(const double* lds, double* L
 // LDS beyond the S tiles: scratch tile of the diagonal-tile routine + eight per-wavefront staging tiles during
 // and after the factorisation; before it, the compact rows of H and one 16-column panel of W = P H^T.
 // SPILL (MT > 10: S does not fit): the pipelined form with only SPILL_CAP tiles of S / L in LDS, see the kernel.
-template <int MT, bool SPILL = false>
+// WIDE (SPILL only): filters of up to 12 row blocks of 16 states; a panel of W is 12 tiles.
+template <int MT, bool SPILL = false, bool WIDE = false>
 struct SolverLds {
+    static_assert(SPILL || !WIDE, "the wide form keeps the factor in a ring");
     static constexpr int M = 16 * MT;
+    static constexpr int PANEL_TILES = WIDE ? 12 : 8;
     static constexpr int COEF_TILES = (15 * M / 2 + 255) / 256;          // ha, hb [M][3], r [M], cs [M] (int)
     // two panels of W (one barrier per panel instead of two) where 160 KB allow it
-    // (SPILL also keeps columns 0..2 of P behind the panels: 2 tiles)
+    // (SPILL also keeps columns 0..2 of P behind the panels: 2 tiles, 3 for 192 rows)
     static constexpr bool TWO_PANELS = SPILL || MT * (MT + 1) / 2 + COEF_TILES + 16 <= 80;
-    static constexpr int EXTRA_TILES = COEF_TILES + (TWO_PANELS ? 16 : 8) + (SPILL ? 2 : 0);
+    static constexpr int EXTRA_TILES = COEF_TILES + (TWO_PANELS ? 2 : 1) * PANEL_TILES + (SPILL ? (WIDE ? 3 : 2) : 0);
     static constexpr int SPILL_CAP = 79 - EXTRA_TILES;                   // tiles of S / L resident at a time
     static constexpr int TILES = (SPILL ? SPILL_CAP : MT * (MT + 1) / 2) + EXTRA_TILES;
 };
@@ -432,13 +435,16 @@ __host__ __device__ constexpr int solver_col_off(int MT, int c) { return (c < MT
 // finished tile whose place has since gone to a later column is read from there (it sits in L2).  Which it is follows
 // from the tile's position in column order and the column being formed -- no flags.  At 12 tile columns 21 of the 78
 // tiles end up outside LDS; during the factorisation only a few operand reads go there, in the backward solve a quarter.
-template <int MT, bool BORDER, bool SPILL = false>
+// WIDE (with SPILL): 9 to 12 row blocks of 16 states.  Panels of W are 12 tiles, so S = H W sees every row of P; the
+// eight wavefronts own row blocks 0..7 of K as before.  Row blocks 8..11 are left to gain_rows_kernel, launched next,
+// which works from the image of the factor; with a border, l (the factor's last row) goes behind the image's tiles.
+template <int MT, bool BORDER, bool SPILL = false, bool WIDE = false>
 __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(FilterView fv, double* __restrict__ K, double* __restrict__ KR,
                                                            double* __restrict__ L, long long sM, long long sNM, int NT,
                                                            double* __restrict__ Lsp = nullptr, long long sSp = 0)
 {
-    extern __shared__ double lds[];                     // SolverLds<MT, SPILL>::TILES tiles of 256 doubles
-    using Lds = SolverLds<MT, SPILL>;
+    extern __shared__ double lds[];                     // SolverLds<MT, SPILL, WIDE>::TILES tiles of 256 doubles
+    using Lds = SolverLds<MT, SPILL, WIDE>;
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar: what depends on it runs on the scalar unit)
     const int li = lane & 15, lk = lane >> 4;
@@ -451,6 +457,7 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
     const int blk = (wave + 7) & 7;
     const bool has_blk = blk < NT;
     const int nl = 16 * NT;
+    constexpr int PANEL = Lds::PANEL_TILES;
     constexpr int CAP = SPILL ? Lds::SPILL_CAP : NTILES;   // tiles of S / L in LDS
     double* scratch = lds + CAP * 256;
     double* stg = scratch + (1 + wave) * 256;           // per-wavefront staging tile (after the build phase)
@@ -491,7 +498,7 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
     // The panels are built by wavefronts 1..7 beside the factorisation, one column ahead of its need (two panel
     // buffers), and wavefront 0 only runs the chain of diagonal tiles; see "Pipelined form" below.
     static_assert(TWO_PANELS, "S and two panels of W do not fit LDS: launch with SPILL");
-    constexpr int RS = 28, UR = 5;                       // rows per pass of the building threads, passes (n <= 128)
+    constexpr int RS = 28, UR = WIDE ? 7 : 5;            // rows per pass of the building threads, passes (n <= 128 / 192)
     const int pt = tid - 64;                             // index among the building threads (wavefront 0: none)
     const bool builder = pt >= 0;
     const int ec = pt & 15, ea = pt >> 4;                // panel column, row within a group of RS rows
@@ -499,7 +506,7 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
     // solves: 1.5 % slower per panel, measured at 10 tile columns), P[a][cs..cs+2] per panel
     constexpr bool PXLDS = SPILL;
     double px[PXLDS ? 1 : UR][3], pf[UR][3];
-    double* pxs = pan0 + 16 * 256;                       // [nl][3] (PXLDS)
+    double* pxs = pan0 + 2 * PANEL * 256;                // [nl][3] (PXLDS)
     // what the border step needs from memory is requested here, a whole factorisation ahead of its use
     double w_alt = 0.0, sigma_alt = 0.0;
     if constexpr (BORDER) {
@@ -548,7 +555,7 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
         // while wavefront 0 updates, factors and inverts the diagonal tile j + 1: what every tile column costs is the
         // chain of wavefront 0, and the build phase disappears behind it.  Same sums in the same order per tile as the
         // right-looking form (columns ascending).
-        auto pan_of = [&](int c) { return pan0 + ((c & 1) ? 8 * 256 : 0); };
+        auto pan_of = [&](int c) { return pan0 + ((c & 1) ? PANEL * 256 : 0); };
         auto write_panel = [&](int p) {                  // panel p of W from the entries of P held in registers
             double* pan = pan_of(p);
             const int q = 16 * p + ec;
@@ -806,6 +813,12 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
                 for (int j = 0; j < MT; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) lvec[16 * j + lk + 4 * r] = -y[j][r];
+                if constexpr (WIDE) {                    // ... and behind the tiles of the image
+#pragma unroll
+                    for (int j = 0; j < MT; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Lsb[(long long)NTILES * 256 + 16 * j + lk + 4 * r] = -y[j][r];
+                }
             }
             __syncthreads();
             double d = 0.0, ll = 0.0;
@@ -864,6 +877,143 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
     }
     if (!(mag < 1.0e300)) atomicOr(fv.status + b, 2);    // S was not positive definite
     SOLVER_STAMP(22);
+}
+
+// Row blocks 8.. of the gain for filters of 9 to 12 row blocks of 16 states, launched behind
+// gain_solver_kernel<MT, BORDER, true, true>, which has left every tile of the factor (L_ij below the diagonal,
+// inv(L_jj) on it) in the image Lsp and, with a border, l behind the tiles.  One wavefront per row block: it forms its
+// tiles of W = P H^T (src/slam/main.cpp:545) itself -- the same six products per entry in the same order as the panels
+// of the solver -- and takes them through the forward solve, the border step and the backward solve of that kernel,
+// every tile read from the image (L2) one product ahead.  256 threads, so the wavefronts have the registers for a
+// whole row of tiles, and two to four filters share a CU.
+template <int MT, bool BORDER>
+__global__ void __launch_bounds__(256, 2) gain_rows_kernel(FilterView fv, double* __restrict__ K, double* __restrict__ KR, long long sNM,
+                                                        int NT, const double* __restrict__ Lsp, long long sSp)
+{
+    constexpr int M = 16 * MT, NTILES = MT * (MT + 1) / 2;
+    __shared__ double cha[3 * M], chb[3 * M], lvec[M];
+    __shared__ int ccs[M];
+    __shared__ double stgs[4][256];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int ldm = fv.ldm, ldn = fv.ldn;
+    const int blk = 8 + wave;
+    const long long rb = (long long)b * ldm;
+    const double* rd = fv.rdiag + rb;
+    const double* Pb = fv.P + (long long)b * ldn * ldn;
+    const double* Lsb = Lsp + (long long)b * sSp;
+    bool border = false;
+    if constexpr (BORDER) border = (fv.m[b] - 1 == M);   // uniform over the workgroup
+    for (int t = tid; t < 3 * M; t += 256) { cha[t] = fv.ha[rb * 3 + t]; chb[t] = fv.hb[rb * 3 + t]; }
+    for (int t = tid; t < M; t += 256) {
+        ccs[t] = fv.hcs[rb + t];
+        lvec[t] = border ? Lsb[(long long)NTILES * 256 + t] : 0.0;
+    }
+    __syncthreads();
+    if (blk >= NT) return;
+    const double* prow = Pb + (long long)(16 * blk + li) * ldn;
+    const double px0 = prow[0], px1 = prow[1], px2 = prow[2];
+    auto tile = [&](int i, int k) { return Lsb + (long long)(k * MT - k * (k - 1) / 2 + (i - k)) * 256; };
+    // tile (blk, c) of W, transposed (accumulator layout of W^T): lane = state row li, measurement rows lk + 4 r
+    auto w_tile = [&](int c) {
+        v4d t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = 16 * c + lk + 4 * r;
+            const double* pf = prow + max(ccs[q], 0);
+            double v = px0 * cha[3 * q];
+            v = fma(px1, cha[3 * q + 1], v);
+            v = fma(px2, cha[3 * q + 2], v);
+            v = fma(pf[0], chb[3 * q], v);
+            v = fma(pf[1], chb[3 * q + 1], v);
+            v = fma(pf[2], chb[3 * q + 2], v);
+            t[r] = v;
+        }
+        return t;
+    };
+    v4d y[MT];
+    // Y^T_j = inv(L_jj) (W^T_j - sum_{k<j} L_jk Y^T_k): as forward_step of gain_solver_kernel
+    auto forward = [&](int j, v4d acc) {
+        double an[4];
+        auto fetch = [&](int k) {
+            const double* ta = tile(j, k);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) an[s] = ta[tsw(li, 4 * s + lk)];
+        };
+        fetch(0);
+#pragma unroll
+        for (int k = 0; k < MT; ++k)
+            if (k < j) {
+                const double a0 = an[0], a1 = an[1], a2 = an[2], a3 = an[3];
+                fetch(k + 1);
+                v4d& c = acc;
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, y[k][0], c, 0, 0, 1);
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, y[k][1], c, 0, 0, 1);
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, y[k][2], c, 0, 0, 1);
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, y[k][3], c, 0, 0, 1);
+            }
+        v4d out = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) out = __builtin_amdgcn_mfma_f64_16x16x4f64(an[s], acc[s], out, 0, 0, 0);
+        return out;
+    };
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        y[j] = forward(j, w_tile(j));
+        __builtin_amdgcn_sched_barrier(0);               // one tile's entries of P in registers at a time
+    }
+
+    double k_alt = 0.0;
+    if constexpr (BORDER) {
+        if (border) {                                    // as in gain_solver_kernel; l comes from the image
+            const double w_a = -prow[2], sigma = Pb[2 * ldn + 2] + rd[M];
+            double d = 0.0, ll = 0.0;
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double lq = lvec[16 * j + lk + 4 * r];
+                    d = fma(y[j][r], lq, d);
+                    ll = fma(lq, lq, ll);
+                }
+            d += __shfl_xor(d, 16); d += __shfl_xor(d, 32);
+            ll += __shfl_xor(ll, 16); ll += __shfl_xor(ll, 32);
+            const double ilam = rsqrt_nr(sigma - ll);
+            k_alt = (w_a - d) * ilam * ilam;
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[j][r] = fma(-k_alt, lvec[16 * j + lk + 4 * r], y[j][r]);
+            if (lk == 0) {                               // the altitude column of K
+                K[(long long)b * sNM + (long long)(16 * blk + li) * ldm + M] = k_alt;
+                if (KR) KR[(long long)b * sNM + (long long)(16 * blk + li) * ldm + M] = k_alt * rd[M];
+            }
+        }
+    }
+    // K^T_j = inv(L_jj)^T (Y^T_j - sum_{k>j} L_kj^T K^T_k),  j = MT-1 .. 0
+    double* stg = stgs[wave];
+    double* Kb = K + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li;
+    double* KRb = KR ? KR + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li : nullptr;
+    double mag = fabs(k_alt);
+#pragma unroll
+    for (int j = MT - 1; j >= 0; --j) {
+        v4d acc = y[j];
+#pragma unroll
+        for (int k = j + 1; k < MT; ++k) acc = tile_mma_regB<true, true>(tile(k, j), y[k], acc, li, lk);
+        y[j] = tile_mma_regB<true, false>(tile(j, j), acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stg[tsw(li, lk + 4 * r)] = y[j][r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double v = stg[tsw(lk + 4 * r, li)];
+            mag += fabs(v);
+            Kb[(long long)(4 * r) * ldm + 16 * j] = v;
+            if (KRb) KRb[(long long)(4 * r) * ldm + 16 * j] = v * rd[16 * j + li];
+        }
+        __builtin_amdgcn_sched_barrier(0);               // (the tiles of one row of products in registers at a time)
+    }
+    if (!(mag < 1.0e300)) atomicOr(fv.status + b, 2);    // S was not positive definite
 }
 
 // Diagonal block of the blocked Cholesky of a large S: factor the 16 MT x 16 MT block at (j0, j0) (lower part

@@ -261,9 +261,14 @@ int max_m(const slamk_handle* h)
 }
 
 constexpr int SOLVER_MAX_MT = 15, SOLVER_MAX_NT = 8;
+// 9 to 12 row blocks of 16 states: the solver's wide form (panels of 12 tiles; row blocks 8.. of K by
+// gain_rows_kernel from the image of the factor); it keeps the factor in the ring form, whose LDS holds up to 15 tile
+// columns with the wider panels
+constexpr int SOLVER_WIDE_NT = 12, SOLVER_WIDE_MIN_MT = 9;
 // more than SOLVER_LDS_MT tile columns: S does not fit LDS and the solver keeps an image of the factor in global memory
 constexpr int SOLVER_LDS_MT = 10;
-constexpr size_t SOLVER_SPILL_IMAGE = (size_t)SOLVER_MAX_MT * (SOLVER_MAX_MT + 1) / 2 * 256;   // doubles per filter
+// doubles per filter: the tiles, and one more for the factor's border row (wide form)
+constexpr size_t SOLVER_SPILL_IMAGE = ((size_t)SOLVER_MAX_MT * (SOLVER_MAX_MT + 1) / 2 + 1) * 256;
 
 // The altitude row is the last measurement row.  When the feature rows of the largest filter fill their 16-row
 // tiles exactly (m - 1 a multiple of 16), the per-filter kernels cover only those tiles and take the altitude row
@@ -272,7 +277,12 @@ bool alt_is_border(int m) { return m > 1 && (m - 1) % 16 == 0; }
 // measurement rows covered by 16-row tiles in the per-filter kernels
 int tiled_rows(int m) { return alt_is_border(m) ? m - 1 : pad16(m); }
 
-bool use_fused_solver(int nl, int m) { return nl <= 16 * SOLVER_MAX_NT && tiled_rows(m) <= 16 * SOLVER_MAX_MT; }
+bool solver_is_wide(int nl) { return nl > 16 * SOLVER_MAX_NT; }
+bool use_fused_solver(int nl, int m)
+{
+    if (tiled_rows(m) > 16 * SOLVER_MAX_MT) return false;
+    return nl <= 16 * SOLVER_MAX_NT || (nl <= 16 * SOLVER_WIDE_NT && tiled_rows(m) >= 16 * SOLVER_WIDE_MIN_MT);
+}
 // the fused covariance update only needs P in LDS (and at most 256 tiled measurement rows for its copy of diag R)
 bool use_fused_joseph(int nl, int m) { return nl <= 16 * SOLVER_MAX_NT && tiled_rows(m) <= 256; }
 
@@ -293,7 +303,7 @@ int ensure_workspaces(slamk_handle* h)
     int need = 0;
     const bool seq = use_seq_update(h, nl);    // the block-sequential update keeps everything in LDS
     if (!seq && !use_fused_solver(nl, mm)) need |= WS_GAIN;
-    if (!seq && use_fused_solver(nl, mm) && tiled_rows(mm) > 16 * SOLVER_LDS_MT) need |= WS_SPILL;
+    if (!seq && use_fused_solver(nl, mm) && (tiled_rows(mm) > 16 * SOLVER_LDS_MT || solver_is_wide(nl))) need |= WS_SPILL;
     if (!seq && !use_fused_joseph(nl, mm)) need |= WS_COV;
     if (h->debug) need |= WS_DENSE;
     need &= ~h->have_ws;
@@ -302,10 +312,12 @@ int ensure_workspaces(slamk_handle* h)
     int rc = 0;
     if ((need & (WS_GAIN | WS_DENSE)) && !h->L) rc |= dalloc(h, &h->L, B * ldm * ldm);
     if (need & WS_GAIN) {
-        rc |= dalloc(h, &h->W, B * ldn * ldm); rc |= dalloc(h, &h->Y, B * ldn * ldm); rc |= dalloc(h, &h->KR, B * ldn * ldm);
+        rc |= dalloc(h, &h->W, B * ldn * ldm); rc |= dalloc(h, &h->Y, B * ldn * ldm);
+        if (!h->KR) rc |= dalloc(h, &h->KR, B * ldn * ldm);
         rc |= dalloc(h, &h->S, B * ldm * ldm); rc |= dalloc(h, &h->Li, B * ldm * ldm);
     }
     if (need & WS_COV) { rc |= dalloc(h, &h->Am, B * ldn * ldn); rc |= dalloc(h, &h->AP, B * ldn * ldn); }
+    if ((need & WS_COV) && !h->KR) rc |= dalloc(h, &h->KR, B * ldn * ldm);     // K R for the covariance update by GEMMs
     if (need & WS_SPILL) rc |= dalloc(h, &h->Lsp, B * SOLVER_SPILL_IMAGE);
     if (need & WS_DENSE) { rc |= dalloc(h, &h->Fm, B * ldn * ldn); rc |= dalloc(h, &h->Hm, B * ldm * ldn); }
     if (rc) return SLAMK_EHIP;
@@ -663,39 +675,48 @@ int run_cholesky_inverse(slamk_handle* h, const Range& rg, int ml, hipStream_t s
     return cholesky_inverse(h, rg.S, rg.L, rg.Li, h->ldm, (long long)h->ldm * h->ldm, rg.B, ml, rg.fv.status, st);
 }
 
-template <int MT, bool BORDER>
-int launch_gain_solver(slamk_handle* h, const Range& rg, int nl, double* Lout, hipStream_t st)
+// KRout: K R beside K for the covariance update by GEMMs (null when the per-filter covariance kernel follows)
+template <int MT, bool BORDER, bool WIDE = false>
+int launch_gain_solver(slamk_handle* h, const Range& rg, int nl, double* Lout, double* KRout, hipStream_t st)
 {
-    constexpr bool SPILL = MT > SOLVER_LDS_MT;
-    const size_t lds = (size_t)SolverLds<MT, SPILL>::TILES * 256 * sizeof(double);
-    { int rc_ = ensure_dynamic_lds(h, reinterpret_cast<const void*>(gain_solver_kernel<MT, BORDER, SPILL>), lds); if (rc_) return rc_; }
-    if (SPILL && !rg.Lsp) return fail(h, SLAMK_EINVAL, "gain solver: no image buffer for %d measurement tiles", MT);
-    const long long sM = (long long)h->ldm * h->ldm, sNM = (long long)h->ldn * h->ldm;
-    hipLaunchKernelGGL((gain_solver_kernel<MT, BORDER, SPILL>), dim3(rg.B), dim3(512), lds, st, rg.fv, rg.K, (double*)nullptr,
-                       Lout, sM, sNM, nl / 16, rg.Lsp, (long long)SOLVER_SPILL_IMAGE);
-    HIPCHK(h, hipGetLastError());
-    return 0;
+    constexpr bool SPILL = MT > SOLVER_LDS_MT || WIDE;
+    if constexpr (WIDE && MT < SOLVER_WIDE_MIN_MT) {
+        return fail(h, SLAMK_EINVAL, "gain solver: %d measurement tiles with more than %d states", MT, 16 * SOLVER_MAX_NT);
+    } else {
+        if (!WIDE && nl > 16 * SOLVER_MAX_NT) return fail(h, SLAMK_EINVAL, "gain solver: %d states need the wide form", nl);
+        const size_t lds = (size_t)SolverLds<MT, SPILL, WIDE>::TILES * 256 * sizeof(double);
+        { int rc_ = ensure_dynamic_lds(h, reinterpret_cast<const void*>(gain_solver_kernel<MT, BORDER, SPILL, WIDE>), lds); if (rc_) return rc_; }
+        if (SPILL && !rg.Lsp) return fail(h, SLAMK_EINVAL, "gain solver: no image buffer for %d measurement tiles", MT);
+        const long long sM = (long long)h->ldm * h->ldm, sNM = (long long)h->ldn * h->ldm;
+        hipLaunchKernelGGL((gain_solver_kernel<MT, BORDER, SPILL, WIDE>), dim3(rg.B), dim3(512), lds, st, rg.fv, rg.K, KRout,
+                           Lout, sM, sNM, nl / 16, rg.Lsp, (long long)SOLVER_SPILL_IMAGE);
+        if constexpr (WIDE)
+            hipLaunchKernelGGL((gain_rows_kernel<MT, BORDER>), dim3(rg.B), dim3(256), 0, st, rg.fv, rg.K, KRout, sNM, nl / 16,
+                               rg.Lsp, (long long)SOLVER_SPILL_IMAGE);
+        HIPCHK(h, hipGetLastError());
+        return 0;
+    }
 }
 
-template <bool BORDER>
-int run_gain_solver_b(slamk_handle* h, const Range& rg, int nl, int mt, double* Lout, hipStream_t st)
+template <bool BORDER, bool WIDE>
+int run_gain_solver_b(slamk_handle* h, const Range& rg, int nl, int mt, double* Lout, double* KRout, hipStream_t st)
 {
     switch (mt) {
-        case 1: return launch_gain_solver<1, BORDER>(h, rg, nl, Lout, st);
-        case 2: return launch_gain_solver<2, BORDER>(h, rg, nl, Lout, st);
-        case 3: return launch_gain_solver<3, BORDER>(h, rg, nl, Lout, st);
-        case 4: return launch_gain_solver<4, BORDER>(h, rg, nl, Lout, st);
-        case 5: return launch_gain_solver<5, BORDER>(h, rg, nl, Lout, st);
-        case 6: return launch_gain_solver<6, BORDER>(h, rg, nl, Lout, st);
-        case 7: return launch_gain_solver<7, BORDER>(h, rg, nl, Lout, st);
-        case 8: return launch_gain_solver<8, BORDER>(h, rg, nl, Lout, st);
-        case 9: return launch_gain_solver<9, BORDER>(h, rg, nl, Lout, st);
-        case 10: return launch_gain_solver<10, BORDER>(h, rg, nl, Lout, st);
-        case 11: return launch_gain_solver<11, BORDER>(h, rg, nl, Lout, st);
-        case 12: return launch_gain_solver<12, BORDER>(h, rg, nl, Lout, st);
-        case 13: return launch_gain_solver<13, BORDER>(h, rg, nl, Lout, st);
-        case 14: return launch_gain_solver<14, BORDER>(h, rg, nl, Lout, st);
-        case 15: return launch_gain_solver<15, BORDER>(h, rg, nl, Lout, st);
+        case 1: return launch_gain_solver<1, BORDER, WIDE>(h, rg, nl, Lout, KRout, st);
+        case 2: return launch_gain_solver<2, BORDER, WIDE>(h, rg, nl, Lout, KRout, st);
+        case 3: return launch_gain_solver<3, BORDER, WIDE>(h, rg, nl, Lout, KRout, st);
+        case 4: return launch_gain_solver<4, BORDER, WIDE>(h, rg, nl, Lout, KRout, st);
+        case 5: return launch_gain_solver<5, BORDER, WIDE>(h, rg, nl, Lout, KRout, st);
+        case 6: return launch_gain_solver<6, BORDER, WIDE>(h, rg, nl, Lout, KRout, st);
+        case 7: return launch_gain_solver<7, BORDER, WIDE>(h, rg, nl, Lout, KRout, st);
+        case 8: return launch_gain_solver<8, BORDER, WIDE>(h, rg, nl, Lout, KRout, st);
+        case 9: return launch_gain_solver<9, BORDER, WIDE>(h, rg, nl, Lout, KRout, st);
+        case 10: return launch_gain_solver<10, BORDER, WIDE>(h, rg, nl, Lout, KRout, st);
+        case 11: return launch_gain_solver<11, BORDER, WIDE>(h, rg, nl, Lout, KRout, st);
+        case 12: return launch_gain_solver<12, BORDER, WIDE>(h, rg, nl, Lout, KRout, st);
+        case 13: return launch_gain_solver<13, BORDER, WIDE>(h, rg, nl, Lout, KRout, st);
+        case 14: return launch_gain_solver<14, BORDER, WIDE>(h, rg, nl, Lout, KRout, st);
+        case 15: return launch_gain_solver<15, BORDER, WIDE>(h, rg, nl, Lout, KRout, st);
         default: return fail(h, SLAMK_EINVAL, "gain solver: %d measurement tiles out of range", mt);
     }
 }
@@ -705,9 +726,13 @@ int run_gain_solver(slamk_handle* h, const Range& rg, int nl, int mm, hipStream_
 {
     ProfScope ps(h, PC_SOLVER, st);
     double* Lout = h->debug ? rg.L : nullptr;         // the factor is only kept for slamk_debug_get
+    double* KRout = use_fused_joseph(nl, mm) ? nullptr : rg.KR;
     const int mt = tiled_rows(mm) / 16;
-    return alt_is_border(mm) ? run_gain_solver_b<true>(h, rg, nl, mt, Lout, st)
-                             : run_gain_solver_b<false>(h, rg, nl, mt, Lout, st);
+    if (solver_is_wide(nl))
+        return alt_is_border(mm) ? run_gain_solver_b<true, true>(h, rg, nl, mt, Lout, KRout, st)
+                                 : run_gain_solver_b<false, true>(h, rg, nl, mt, Lout, KRout, st);
+    return alt_is_border(mm) ? run_gain_solver_b<true, false>(h, rg, nl, mt, Lout, KRout, st)
+                             : run_gain_solver_b<false, false>(h, rg, nl, mt, Lout, KRout, st);
 }
 
 // The gate and the mean update ride in the covariance update kernel when launches are what the step costs (few

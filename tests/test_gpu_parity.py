@@ -116,6 +116,25 @@ def test_fused_path_tile_count_edges(nf, ref_fraction, form):
     print("nf=%d ref=%.1f form=%d worst rel err %.2e" % (nf, ref_fraction, form, worst))
 
 
+@pytest.mark.parametrize("nf,ref_fraction,form", [(40, 0.5, 0), (40, 0.0, 0), (40, 0.0, 1), (40, 1.0, 0), (43, 0.5, 0),
+                                                  (45, 0.3, 0), (47, 0.5, 0), (50, 0.0, 0), (52, 0.0, 0), (56, 0.0, 0),
+                                                  (58, 0.0, 1), (60, 0.0, 0), (61, 0.0, 0), (48, 0.5, 0)])
+def test_wide_gain_solver_edges(nf, ref_fraction, form):
+    """Nine to twelve 16-row blocks of the state (n = 129 .. 189) with up to 240 tiled measurement rows: the gain comes
+    from the per-filter solver's wide form (row blocks 8.. in a second pass) and feeds the covariance update by GEMMs.
+    n = 129 (one row in the ninth block), n = 144 (no padding rows), the altitude row as border with 10, 12, 13, 14
+    and 15 tile columns, all-reflection rows (m = 241: 16 tile columns, back on the blocked path), and both sides of
+    the range's end (60 features: n = 189, m = 241 as 240 + border; 61: n = 192, m = 245)."""
+    st = synth.gen_stream(seed=170 + nf, nf=nf, steps=31, churn=False, ref_fraction=ref_fraction)
+    so, _ = helpers.run_oracle(st)
+    p = ekf.default_params()
+    p.update_form = form
+    fb = ekf.FilterBatch(max_features=nf, batch=1, params=p)
+    sg = helpers.run_gpu(st, fb)
+    worst = compare_snaps(so, sg)
+    print("nf=%d ref=%.1f form=%d worst rel err %.2e" % (nf, ref_fraction, form, worst))
+
+
 def test_map_growing_through_every_path_in_one_handle():
     """One handle whose map grows 30 -> 37 -> 45 features: per-filter kernels, then the GEMM gain with the fused
     covariance update, then the all-GEMM path; the larger paths' workspaces first appear in the middle of the run."""
