@@ -277,6 +277,8 @@ bool alt_is_border(int m) { return m > 1 && (m - 1) % 16 == 0; }
 // measurement rows covered by 16-row tiles in the per-filter kernels
 int tiled_rows(int m) { return alt_is_border(m) ? m - 1 : pad16(m); }
 
+// measurement rows (padded) up to which eye_minus_kh_rows_kernel holds its 16 rows of K in LDS (64 KB)
+constexpr int KH_ONE_PASS_MAX_ML = 512;
 bool solver_is_wide(int nl) { return nl > 16 * SOLVER_MAX_NT; }
 bool use_fused_solver(int nl, int m)
 {
@@ -912,6 +914,8 @@ int run_update(slamk_handle* h, const Range& rg, const double* qbw, const double
         return 0;
     }
     const RowSparse MH{rg.fv.ha, rg.fv.hb, rg.fv.hcs, ldm, 0};
+    // covariance update by GEMMs with rows of K that fit LDS four per wavefront: A = I - K H and dx = K e in one pass
+    const bool kh_one_pass = !use_fused_joseph(nl, mm) && ml <= KH_ONE_PASS_MAX_ML;
     {
     ProfScope ps(h, PC_STRUCT_GAIN, st);
     if (!use_fused_solver(nl, mm)) {     // the fused solver forms W and S in LDS itself
@@ -943,10 +947,19 @@ int run_update(slamk_handle* h, const Range& rg, const double* qbw, const double
         {
         ProfScope ps(h, PC_STRUCT_GAIN, st);
         // A = I - K H                                (updateP, :563-565)
-        hipLaunchKernelGGL(eye_minus_kh_kernel, dim3((nl + 63) / 64, (nl + 4 * STRUCT_RPW - 1) / (4 * STRUCT_RPW), B),
-                           dim3(256), 0, st, rg.fv, rg.K, ldm, sNM, rg.Am, ldn, sN, nl, nl, 0, STRUCT_RPW);
-        hipLaunchKernelGGL(eye_minus_kh_xcols_kernel, dim3((nl + 3) / 4, B), dim3(256), 0, st, rg.fv, rg.K, ldm, sNM, rg.Am,
-                           ldn, sN, nl, 0, ml);
+        if (kh_one_pass) {                               // ... and dx = K e (:228) on the same pass over K
+            const size_t lkh = (size_t)4 * KH_ROWS * ml * sizeof(double);
+            int rc_ = ensure_dynamic_lds(h, reinterpret_cast<const void*>(eye_minus_kh_rows_kernel),
+                                         (size_t)4 * KH_ROWS * KH_ONE_PASS_MAX_ML * sizeof(double));
+            if (rc_) return rc_;
+            hipLaunchKernelGGL(eye_minus_kh_rows_kernel, dim3((nl + 4 * KH_ROWS - 1) / (4 * KH_ROWS), B), dim3(256), lkh, st,
+                               rg.fv, rg.K, ldm, sNM, rg.Am, ldn, sN, nl, ml, rg.dx);
+        } else {
+            hipLaunchKernelGGL(eye_minus_kh_kernel, dim3((nl + 63) / 64, (nl + 4 * STRUCT_RPW - 1) / (4 * STRUCT_RPW), B),
+                               dim3(256), 0, st, rg.fv, rg.K, ldm, sNM, rg.Am, ldn, sN, nl, nl, 0, STRUCT_RPW);
+            hipLaunchKernelGGL(eye_minus_kh_xcols_kernel, dim3((nl + 3) / 4, B), dim3(256), 0, st, rg.fv, rg.K, ldm, sNM,
+                               rg.Am, ldn, sN, nl, 0, ml);
+        }
         }
         {
         ProfScope ps(h, PC_GEMM_COV, st);
@@ -973,7 +986,7 @@ int run_update(slamk_handle* h, const Range& rg, const double* qbw, const double
     }
     ProfScope ps_tail(h, PC_FEATURE, st);
     // dx = K e, gate, mean update                (main.cpp:228-232)
-    if (!use_fused_joseph(nl, mm))      // the fused covariance update has already formed dx
+    if (!use_fused_joseph(nl, mm) && !kh_one_pass)      // the fused covariance update has already formed dx
         hipLaunchKernelGGL(gain_kx_kernel, dim3((nl + 15) / 16, B), dim3(256), 0, st, rg.fv, rg.K, ldm, rg.dx, ml);
     if (!use_fused_joseph(nl, mm) || !fuse_apply(B))
         hipLaunchKernelGGL(gain_apply_kernel, dim3(B), dim3(256), 0, st, rg.fv, rg.dx, applied);

@@ -478,4 +478,85 @@ __global__ void __launch_bounds__(256) eye_minus_kh_xcols_kernel(FilterView fv, 
     }
 }
 
+// A = I - K H (updateP, src/slam/main.cpp:563-565) and dx = K e (:228) in ONE pass over K, for filters whose rows of K
+// fit LDS (the three kernels above and gain_kx_kernel read K once each).  A wavefront takes KH_ROWS rows of the gain
+// into LDS while it sums their position columns and their products with the innovation, then forms those rows of A with
+// its lanes along the columns.  Same sums in the same order as eye_minus_kh_kernel, eye_minus_kh_xcols_kernel and
+// gain_kx_kernel.  grid (ceil(nl / (4 KH_ROWS)), B), 256 threads, 4 KH_ROWS ml doubles of dynamic LDS; no barrier: a
+// wavefront only reads what it wrote itself.
+constexpr int KH_ROWS = 4;
+__global__ void __launch_bounds__(256) eye_minus_kh_rows_kernel(FilterView fv, const double* __restrict__ K, int ldk,
+                                                                 long long sK, double* __restrict__ A, int lda,
+                                                                 long long sA, int nl, int ml, double* __restrict__ dx)
+{
+    extern __shared__ double kh_rows[];                  // [4][KH_ROWS][ml]
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j0 = (blockIdx.x * 4 + wave) * KH_ROWS;
+    if (j0 >= nl) return;
+    const int nf = fv.nf[b];
+    double* kw = kh_rows + (size_t)wave * KH_ROWS * ml;
+    const double* Kb = K + (long long)b * sK;
+    const double* ha = fv.ha + (long long)b * fv.ldm * 3;
+    const double* e = fv.e + (long long)b * fv.ldm;
+    double s0[KH_ROWS], s1[KH_ROWS], s2[KH_ROWS], sd[KH_ROWS];
+#pragma unroll
+    for (int r = 0; r < KH_ROWS; ++r) s0[r] = s1[r] = s2[r] = sd[r] = 0.0;
+    for (int q = lane; q < ml; q += 64) {
+        const double a0 = ha[3 * q], a1 = ha[3 * q + 1], a2 = ha[3 * q + 2], eq = e[q];
+#pragma unroll
+        for (int r = 0; r < KH_ROWS; ++r) {
+            const double k = j0 + r < nl ? Kb[(long long)(j0 + r) * ldk + q] : 0.0;
+            kw[r * ml + q] = k;
+            s0[r] = fma(k, a0, s0[r]);
+            s1[r] = fma(k, a1, s1[r]);
+            s2[r] = fma(k, a2, s2[r]);
+            sd[r] += k * eq;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < KH_ROWS; ++r)
+        for (int o = 32; o > 0; o >>= 1) {
+            s0[r] += __shfl_xor(s0[r], o);
+            s1[r] += __shfl_xor(s1[r], o);
+            s2[r] += __shfl_xor(s2[r], o);
+            sd[r] += __shfl_xor(sd[r], o);
+        }
+    __builtin_amdgcn_wave_barrier();                     // (the rows in LDS are read by other lanes of this wavefront)
+    if (dx && lane == 0) {                               // bias rows are skipped, as in gain_kx_kernel
+#pragma unroll
+        for (int r = 0; r < KH_ROWS; ++r)
+            if (j0 + r < 6 + 3 * nf) dx[(long long)b * fv.ldn + j0 + r] = sd[r];
+    }
+    double* Ab = A + (long long)b * sA;
+    for (int l = lane; l < nl; l += 64) {
+        int frow = 0, cnt = 0, c = 0;
+        if (l >= 6 && l < 6 + 3 * nf) {
+            const int i = (l - 6) / 3;
+            c = (l - 6) - 3 * i;
+            frow = fv.rowoff[(long long)b * fv.F + i];
+            cnt = fv.isref[(long long)b * fv.F + i] ? 6 : 4;
+        }
+        const double* hb = fv.hb + ((long long)b * fv.ldm + frow) * 3 + c;
+        double h[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) h[t] = (t < cnt) ? hb[3 * t] : 0.0;
+#pragma unroll
+        for (int r = 0; r < KH_ROWS; ++r) {
+            const int j = j0 + r;
+            if (j >= nl) break;
+            double acc = 0.0;
+            if (l < 3) acc = l == 0 ? s0[r] : (l == 1 ? s1[r] : s2[r]);
+            else if (cnt) {
+                const double* kr = kw + r * ml + frow;
+                acc = kr[0] * h[0];
+#pragma unroll
+                for (int t = 1; t < 6; ++t)
+                    if (t < cnt) acc = fma(kr[t], h[t], acc);
+            }
+            Ab[(long long)j * lda + l] = (j == l ? 1.0 : 0.0) - acc;
+        }
+    }
+}
+
 }  // namespace slamk
