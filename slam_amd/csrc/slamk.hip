@@ -95,6 +95,11 @@ struct slamk_handle {
     std::vector<hipStream_t> gstreams;
     std::vector<hipEvent_t> gdone;
     hipEvent_t fork = nullptr;
+    // blocked Cholesky of one large S: the trailing update right of the next outer panel runs on a stream of its own
+    // beside that panel's factorisation (handles made by slamk_create only)
+    bool chol_lookahead = false;
+    hipStream_t chol_side = nullptr;
+    hipEvent_t chol_panel_done = nullptr, chol_rest_done = nullptr;
     // slamk_step_dev in graph mode: captured launch sequences, keyed by everything baked into the launches
     bool debug = false;                    // materialise dense F, H and L for slamk_debug_get*
     bool graph_mode = false;
@@ -614,19 +619,60 @@ int cholesky_inverse(slamk_handle* h, double* Sp, double* Lp, double* Lip, int l
     // Blocked right-looking Cholesky on two levels: inside an outer panel of OB columns the updates are of rank
     // CHOL_NB and stay inside the panel; the columns right of the panel take one rank-OB update when the panel is
     // complete, which reads and writes the large trailing matrix OB / CHOL_NB times less often.
+    // One large matrix (SLAMK_CHOL_LOOKAHEAD=0 turns it off): that update is cut in two.  The columns of the NEXT panel
+    // are updated on the launch stream and the panel's factorisation -- a chain of one-workgroup kernels and narrow
+    // products -- follows at once; the columns right of it are updated on a second stream beside that chain.  The two
+    // parts write disjoint columns; the part on the launch stream for panel p + 1 waits for the second stream's part of
+    // panel p, which wrote those columns before.  Same products and sums per element as the single update.
+    static const bool lookahead_env = [] { const char* e = getenv("SLAMK_CHOL_LOOKAHEAD"); return !e || atoi(e) != 0; }();
+    bool ahead = lookahead_env && h->chol_lookahead && B == 1 && ml > 3 * OB;
+    if (ahead && !h->chol_side) {
+        // the second stream leaves a few CUs alone, so that a one-workgroup kernel of the chain on the launch stream
+        // finds a whole CU's LDS free while the wide product runs (otherwise it waits for that product to drain)
+        hipDeviceProp_t prop;
+        HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
+        const int ncu = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+        static const int spare = [] { const char* e = getenv("SLAMK_CHOL_SPARE_CUS"); return e ? atoi(e) : 32; }();
+        for (int c = std::min(spare, ncu - 1); c < ncu; ++c) mask[c / 32] |= 1u << (c % 32);
+        HIPCHK(h, hipExtStreamCreateWithCUMask(&h->chol_side, (uint32_t)mask.size(), mask.data()));
+        HIPCHK(h, hipEventCreateWithFlags(&h->chol_panel_done, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->chol_rest_done, hipEventDisableTiming));
+    }
+    bool rest_pending = false;                           // the second stream holds an update the launch stream has not joined
     for (int J0 = 0; J0 < ml; J0 += OB) {
         const int J1 = std::min(ml, J0 + OB);
         int rc = chol_outer_panel(h, SymView{Sp, ldm, sM, 0, 0}, Lp, Lip, ldm, sM, B, ml, J0, J1, status, st);
         if (rc) return rc;
         const int remo = ml - J1;
-        if (remo > 0) {          // the rest of the trailing matrix: one update of rank J1 - J0
-            ProfScope ps(h, PC_GEMM_CHOL, st);
-            const long long oL = (long long)J1 * ldm + J0, oS = (long long)J1 * ldm + J1;
+        if (remo <= 0) break;
+        ProfScope ps(h, PC_GEMM_CHOL, st);
+        const long long oL = (long long)J1 * ldm + J0, oS = (long long)J1 * ldm + J1;
+        const int J2 = std::min(ml, J1 + OB);
+        if (ahead && ml - J2 > 0) {
+            // columns [J2, ml): rows from J2 down, on the second stream
+            HIPCHK(h, hipEventRecord(h->chol_panel_done, st));
+            HIPCHK(h, hipStreamWaitEvent(h->chol_side, h->chol_panel_done, 0));
+            const long long oL2 = (long long)J2 * ldm + J0, oS2 = (long long)J2 * ldm + J2;
+            HIPCHK(h, (launch_gemm<true, EPI_NONE, true, TRI_NONE>(
+                          gargs(Lp + oL2, ldm, sM, Lp + oL2, ldm, sM, Sp + oS2, ldm, sM, ml - J2, ml - J2, J1 - J0, -1.0, 1.0),
+                          B, h->chol_side)));
+            // columns [J1, J2) of the next panel: after the previous panel's update of the same columns
+            if (rest_pending) HIPCHK(h, hipStreamWaitEvent(st, h->chol_rest_done, 0));
+            HIPCHK(h, hipEventRecord(h->chol_rest_done, h->chol_side));
+            rest_pending = true;
+            HIPCHK(h, (launch_gemm<true, EPI_NONE, true, TRI_NONE>(
+                          gargs(Lp + oL, ldm, sM, Lp + oL, ldm, sM, Sp + oS, ldm, sM, remo, J2 - J1, J1 - J0, -1.0, 1.0),
+                          B, st)));
+        } else {
+            if (rest_pending) { HIPCHK(h, hipStreamWaitEvent(st, h->chol_rest_done, 0)); rest_pending = false; }
+            // the rest of the trailing matrix: one update of rank J1 - J0
             HIPCHK(h, (launch_gemm<true, EPI_NONE, true, TRI_NONE>(
                           gargs(Lp + oL, ldm, sM, Lp + oL, ldm, sM, Sp + oS, ldm, sM, remo, remo, J1 - J0, -1.0, 1.0),
                           B, st)));
         }
     }
+    if (rest_pending) HIPCHK(h, hipStreamWaitEvent(st, h->chol_rest_done, 0));
     return chol_block_inverses(h, Sp, ldm, sM, false, Lp, Lip, ldm, sM, B, ml, st);
 }
 
@@ -1121,6 +1167,7 @@ int slamk_create(const slamk_params* p, int max_features, int batch, int device,
     slamk_handle* h = new slamk_handle();
     if (p) h->prm = *p; else slamk_default_params(&h->prm);
     h->B = batch; h->F = std::max(1, max_features); h->device = device;
+    h->chol_lookahead = true;
     h->ldn = pad16(9 + 3 * h->F);
     h->ldm = pad16(1 + 6 * h->F);
     h->hf.resize(batch);
@@ -1173,6 +1220,9 @@ int slamk_destroy(slamk_handle* h)
     for (auto g : h->gstreams) (void)hipStreamDestroy(g);
     for (auto e : h->gdone) (void)hipEventDestroy(e);
     if (h->fork) (void)hipEventDestroy(h->fork);
+    if (h->chol_side) (void)hipStreamDestroy(h->chol_side);
+    if (h->chol_panel_done) (void)hipEventDestroy(h->chol_panel_done);
+    if (h->chol_rest_done) (void)hipEventDestroy(h->chol_rest_done);
     for (auto& r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : h->prof_pool) (void)hipEventDestroy(e);
     delete h;
