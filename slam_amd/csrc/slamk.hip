@@ -626,6 +626,10 @@ int cholesky_inverse(slamk_handle* h, double* Sp, double* Lp, double* Lip, int l
     // panel p, which wrote those columns before.  Same products and sums per element as the single update.
     static const bool lookahead_env = [] { const char* e = getenv("SLAMK_CHOL_LOOKAHEAD"); return !e || atoi(e) != 0; }();
     bool ahead = lookahead_env && h->chol_lookahead && B == 1 && ml > 3 * OB;
+    if (ahead) {                                         // not inside a stream capture (graph mode)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) ahead = false;
+    }
     if (ahead && !h->chol_side) {
         // the second stream leaves a few CUs alone, so that a one-workgroup kernel of the chain on the launch stream
         // finds a whole CU's LDS free while the wide product runs (otherwise it waits for that product to drain)
