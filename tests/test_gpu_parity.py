@@ -470,11 +470,12 @@ def test_graph_mode_replays_the_same_iteration():
         fb.close()
 
 
-@pytest.mark.parametrize("nfs", [(4, 11, 7), (32, 5, 20, 33)])
+@pytest.mark.parametrize("nfs", [(4, 11, 7), (32, 5, 20, 33), (45, 12, 40, 33)])
 def test_mixed_feature_counts_in_one_batch(nfs):
     """Filters with different nf share one launch (dimensions are padded to the batch maximum); the second set is
     launched with seven row blocks (the covariance update with four wavefronts per filter) for filters of one to
-    seven."""
+    seven; the third with ten (the gain solver's wide form and its second kernel for row blocks 8 and 9, which the
+    smaller filters of the batch do not have)."""
     sts = [synth.gen_stream(seed=30 + i, nf=nf, steps=7, churn=False) for i, nf in enumerate(nfs)]
     sts.append(synth.gen_stream(seed=34, nf=3, steps=7, churn=False, drop_at=3, drop_count=3))   # empties at the 2nd frame
     B = len(sts)
@@ -626,7 +627,7 @@ def test_full_size_batch_properties():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("nf,ref_fraction", [(4, 0.5), (8, 0.5), (20, 0.5), (24, 0.0), (28, 1.0), (32, 0.5), (38, 0.0),
-                                             (36, 0.5), (36, 1.0), (39, 1.0)])
+                                             (36, 0.5), (36, 1.0), (39, 1.0), (40, 0.0), (44, 0.5), (47, 1.0)])
 def test_identical_filters_give_identical_results(nf, ref_fraction):
     """1024 filters with the same inputs: the per-filter kernels run the same instructions on the same data in every
     workgroup, so every covariance and state must equal those of filter 0 bit for bit, whatever CU a workgroup lands on
