@@ -626,8 +626,8 @@ def main():
                            "large_map": large_map(torch, dev),
                            "ceilings": ceilings(torch, dev),
                            "sweep": [sweep_point(torch, dev, nf_, B_) for nf_, B_ in
-                                     ((8, 4096), (20, 4096), (32, 512), (32, 16384), (36, 1024), (40, 1024), (48, 1024),
-                                      (60, 1024))],
+                                     ((8, 4096), (20, 4096), (32, 512), (32, 16384), (36, 1024), (40, 1024), (44, 1024),
+                                      (48, 1024), (52, 1024), (60, 1024))],
                            # update_form = 2 (not the default, not what `value` measures): the measurement rows 16 at a
                            # time against the covariance in LDS; same posterior up to rounding, n <= 160 only
                            "block_sequential_form": {

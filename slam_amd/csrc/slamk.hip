@@ -269,7 +269,8 @@ constexpr int SOLVER_MAX_MT = 15, SOLVER_MAX_NT = 8;
 // 9 to 12 row blocks of 16 states: the solver's wide form (panels of 12 tiles; row blocks 8.. of K by
 // gain_rows_kernel from the image of the factor); it keeps the factor in the ring form, whose LDS holds up to 15 tile
 // columns with the wider panels
-constexpr int SOLVER_WIDE_NT = 12, SOLVER_WIDE_MIN_MT = 9;
+// (more than 128 states are at least 40 features, i.e. at least 161 measurement rows: 10 tile columns)
+constexpr int SOLVER_WIDE_NT = 12, SOLVER_WIDE_MIN_MT = 10;
 // more than SOLVER_LDS_MT tile columns: S does not fit LDS and the solver keeps an image of the factor in global memory
 constexpr int SOLVER_LDS_MT = 10;
 // doubles per filter: the tiles, and one more for the factor's border row (wide form)
