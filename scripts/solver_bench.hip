@@ -7,9 +7,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#ifndef SB_STAMP_BLOCK
+#define SB_STAMP_BLOCK 2000
+#endif
 #ifdef STAMPS
 __device__ unsigned long long g_stamps[8][32];
-#define SOLVER_STAMP(i) do { if (blockIdx.x == 2000 && (threadIdx.x & 63) == 0) g_stamps[threadIdx.x >> 6][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SOLVER_STAMP(i) do { if (blockIdx.x == SB_STAMP_BLOCK && (threadIdx.x & 63) == 0) g_stamps[threadIdx.x >> 6][i] = __builtin_amdgcn_s_memtime(); } while (0)
 #endif
 #ifndef SB_HEADER
 #define SB_HEADER "../slam_amd/csrc/gain_solver.hip.h"
@@ -78,7 +81,9 @@ int main()
         printf("%s: %.3f ms\n", VARIANT, ms);
 #ifdef SB_WIDE
         hipEventRecord(e0);
-        gain_rows_kernel<MT, BORDER><<<B, 256>>>(fv, K, nullptr, sNM, NT, Lsp, sSp);
+        const size_t lr = (size_t)gain_rows_lds_tiles(MT) * 256 * 8;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gain_rows_kernel<MT, BORDER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr);
+        gain_rows_kernel<MT, BORDER><<<B, 256, lr>>>(fv, K, nullptr, sNM, NT, 0, 1, Lsp, sSp);
         hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
         printf("%s rows 8..: %.3f ms (%s)\n", VARIANT, ms, hipGetErrorString(hipGetLastError()));

@@ -435,9 +435,10 @@ __host__ __device__ constexpr int solver_col_off(int MT, int c) { return (c < MT
 // finished tile whose place has since gone to a later column is read from there (it sits in L2).  Which it is follows
 // from the tile's position in column order and the column being formed -- no flags.  At 12 tile columns 21 of the 78
 // tiles end up outside LDS; during the factorisation only a few operand reads go there, in the backward solve a quarter.
-// WIDE (with SPILL): 9 to 12 row blocks of 16 states.  Panels of W are 12 tiles, so S = H W sees every row of P; the
-// eight wavefronts own row blocks 0..7 of K as before.  Row blocks 8..11 are left to gain_rows_kernel, launched next,
-// which works from the image of the factor; with a border, l (the factor's last row) goes behind the image's tiles.
+// WIDE (with SPILL): 9 to 12 row blocks of 16 states.  Panels of W are 12 tiles, so S = H W sees every row of P, and the
+// kernel only factors S: the two solves for K are left to gain_rows_kernel, launched next, which works from the image
+// of the factor (a row of tiles of Y^T per wavefront for 15 tile columns is 120 registers this kernel does not have
+// beside its panels, and its finished tiles mostly sit in L2 by then: the solves ran at a sixth of their speed here).
 template <int MT, bool BORDER, bool SPILL = false, bool WIDE = false>
 __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(FilterView fv, double* __restrict__ K, double* __restrict__ KR,
                                                            double* __restrict__ L, long long sM, long long sNM, int NT,
@@ -509,7 +510,7 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
     double* pxs = pan0 + 2 * PANEL * 256;                // [nl][3] (PXLDS)
     // what the border step needs from memory is requested here, a whole factorisation ahead of its use
     double w_alt = 0.0, sigma_alt = 0.0;
-    if constexpr (BORDER) {
+    if constexpr (BORDER && !WIDE) {
         w_alt = has_blk ? -Pb[(long long)min(16 * blk + li, nl - 1) * ldn + 2] : 0.0;
         sigma_alt = Pb[2 * ldn + 2] + rd[M];
     }
@@ -694,10 +695,10 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
                 for (int r = 0; r < 4; ++r) Kpark[(long long)li * ldm + 16 * c + lk + 4 * r] = pan[blk * 256 + tsw(li, lk + 4 * r)];
             };
             __syncthreads();                             // panel 0 is in LDS
-            if (has_blk) park(0);
+            if constexpr (!WIDE) { if (has_blk) park(0); }
             __syncthreads();                             // column 0 of S and panel 1 are in LDS
             SOLVER_STAMP(1);
-            if (has_blk && 1 < MT) park(1);
+            if constexpr (!WIDE) { if (has_blk && 1 < MT) park(1); }
             {
                 v4d a0;
 #pragma unroll
@@ -709,7 +710,7 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
                 __syncthreads();                         // A
                 if (j + 1 < MT) panel_tile(j + 1, j);
                 __syncthreads();                         // B
-                if (has_blk && j + 2 < MT) park(j + 2);
+                if constexpr (!WIDE) { if (has_blk && j + 2 < MT) park(j + 2); }
                 if (j + 1 < MT) {                        // the update with column j stays in registers
                     double* tjj = tslot(j + 1, j + 1);
                     const double* tp = tslot(j + 1, j);
@@ -723,9 +724,11 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
                 SOLVER_STAMP(2 + j);
             }
             __syncthreads();
-            if (has_blk) {
+            if constexpr (!WIDE) {
+                if (has_blk) {
 #pragma unroll
-                for (int j = 0; j < MT; ++j) y[j] = forward_step(j, late_tile(j), THR_END);
+                    for (int j = 0; j < MT; ++j) y[j] = forward_step(j, late_tile(j), THR_END);
+                }
             }
         } else {
             // wavefront 4 shares its SIMD with wavefront 0: it takes no panel tiles and no updates of column j + 1,
@@ -744,7 +747,7 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
             if (1 < MT) load_panel(1);
             __syncthreads();                             // panel 0 is in LDS
             for (int i = wk6; i < MT; i += 7) form_tile(i, 0);
-            if (has_blk) take_y(0);
+            if constexpr (!WIDE) { if (has_blk) take_y(0); }
             if (1 < MT) {
                 write_panel(1);
                 if (2 < MT) load_panel(2);
@@ -753,7 +756,7 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
             SOLVER_STAMP(1);
             if (1 < MT) {
                 for (int i = 1 + wk6; i < MT; i += 7) form_tile(i, 1);
-                if (has_blk) take_y(1);
+                if constexpr (!WIDE) { if (has_blk) take_y(1); }
             }
             if (2 < MT) {
                 write_panel(2);
@@ -776,9 +779,9 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
                         form_tile(i, j + 2);
                         update_tile(i, j + 2, 0, j, thr_at(j + 2));
                     }
-                    if (has_blk) take_y(j + 2);
+                    if constexpr (!WIDE) { if (has_blk) take_y(j + 2); }
                 }
-                if (has_blk) y[j] = forward_step(j, y[j], thr_at(j + 2));
+                if constexpr (!WIDE) { if (has_blk) y[j] = forward_step(j, y[j], thr_at(j + 2)); }
                 SOLVER_STAMP(2 + j);
             }
             __syncthreads();
@@ -799,6 +802,7 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
         if (Lb) store_offdiag_tiles<MT>(lds, Lb, ldm, wave, lane);
     }
     SOLVER_STAMP(20);
+    if constexpr (WIDE) return;                          // K: gain_rows_kernel
 
     // ---- the altitude row as a border of the factored block -----------------------------------------------
     double k_alt = 0.0;                                  // K[16 blk + li][M], the same in the four lane groups
@@ -813,12 +817,6 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
                 for (int j = 0; j < MT; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) lvec[16 * j + lk + 4 * r] = -y[j][r];
-                if constexpr (WIDE) {                    // ... and behind the tiles of the image
-#pragma unroll
-                    for (int j = 0; j < MT; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) Lsb[(long long)NTILES * 256 + 16 * j + lk + 4 * r] = -y[j][r];
-                }
             }
             __syncthreads();
             double d = 0.0, ll = 0.0;
@@ -879,142 +877,252 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
     SOLVER_STAMP(22);
 }
 
-// Row blocks 8.. of the gain for filters of 9 to 12 row blocks of 16 states, launched behind
-// gain_solver_kernel<MT, BORDER, true, true>, which has left every tile of the factor (L_ij below the diagonal,
-// inv(L_jj) on it) in the image Lsp and, with a border, l behind the tiles.  One wavefront per row block: it forms its
-// tiles of W = P H^T (src/slam/main.cpp:545) itself -- the same six products per entry in the same order as the panels
-// of the solver -- and takes them through the forward solve, the border step and the backward solve of that kernel,
-// every tile read from the image (L2) one product ahead.  256 threads, so the wavefronts have the registers for a
-// whole row of tiles, and two to four filters share a CU.
+// K for filters of 9 to 12 row blocks of 16 states, launched behind gain_solver_kernel<MT, BORDER, true, true>, which
+// only factors S for them and leaves every tile of the factor (L_ij below the diagonal, inv(L_jj) on it) in the image
+// Lsp.  A workgroup of four wavefronts takes up to four row blocks of W / K from blk0 on, one per wavefront:
+//   - each wavefront forms its tiles of W = P H^T (src/slam/main.cpp:545) itself: the same six products per entry in
+//     the same order as the panels of the solver;
+//   - the forward solve walks the rows of the factor, the backward solve its columns; the four wavefronts need the same
+//     tiles at the same time, so the workgroup streams them through LDS: all 256 threads copy row j + 1 (column j - 1)
+//     of tiles from the image (L2) into one buffer while the products of row j run from the other: one barrier and one
+//     L2 latency per row of tiles instead of one per product;
+//   - the border step needs l = -(row 2 of Y_f)^T, which the wavefront with row block 0 has after its forward solve:
+//     with BORDER the launch with blk0 = 0 (one workgroup per filter, G = 1) passes it on in LDS and leaves it
+//     behind the image's tiles for the launch with blk0 = 4, which follows on the same stream; without, one launch
+//     (blk0 = 0) covers all row blocks.
+// 256 registers per wavefront hold a whole row of tiles of Y^T; (2 MT + 5) tiles of LDS: two workgroups per CU.
 template <int MT, bool BORDER>
 __global__ void __launch_bounds__(256, 2) gain_rows_kernel(FilterView fv, double* __restrict__ K, double* __restrict__ KR, long long sNM,
-                                                        int NT, const double* __restrict__ Lsp, long long sSp)
+                                                           int NT, int blk0, int G, double* __restrict__ Lsp, long long sSp)
 {
     constexpr int M = 16 * MT, NTILES = MT * (MT + 1) / 2;
-    __shared__ double cha[3 * M], chb[3 * M], lvec[M];
-    __shared__ int ccs[M];
-    __shared__ double stgs[4][256];
-    const int b = blockIdx.x;
+    extern __shared__ double lds[];                     // gain_rows_lds_tiles(MT) tiles
+    double* buf[2] = {lds, lds + MT * 256};              // a row / column of tiles of the factor each
+    double* stgs = lds + 2 * MT * 256;                   // one staging tile per wavefront
+    double* lvec = stgs + 4 * 256;                       // [M]
+    // before the solves the buffers hold the compact rows of H: ha, hb [M][3], cs [M] (6.5 M doubles of 512 MT)
+    double* cha = lds;
+    double* chb = cha + 3 * M;
+    int* ccs = reinterpret_cast<int*>(chb + 3 * M);
+    // The G workgroups of a filter stream the same image: they sit next to each other on one XCD (consecutive workgroup
+    // numbers go round the eight XCDs), so the image comes from HBM once and from that XCD's L2 after that.
+    const int wg = (int)blockIdx.x >> 3, by = wg % G;
+    const int b = (wg / G) * 8 + ((int)blockIdx.x & 7);
+    if (b >= fv.B) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const int ldm = fv.ldm, ldn = fv.ldn;
-    const int blk = 8 + wave;
+    // (row blocks dealt to the workgroups of a launch round robin: 9 row blocks are 4, then 3 + 2; which wavefronts --
+    // which SIMDs -- get them rotates with the workgroup, so that two workgroups sharing a CU load its SIMDs evenly)
+    const int slot = (wave + b + 2 * by) & 3;
+    const int blk = blk0 + by + G * slot;
+    const bool has_blk = blk < NT;
+    const bool first = blk0 == 0 && by == 0;             // this workgroup holds row block 0
     const long long rb = (long long)b * ldm;
     const double* rd = fv.rdiag + rb;
     const double* Pb = fv.P + (long long)b * ldn * ldn;
-    const double* Lsb = Lsp + (long long)b * sSp;
+    double* Lsb = Lsp + (long long)b * sSp;
     bool border = false;
     if constexpr (BORDER) border = (fv.m[b] - 1 == M);   // uniform over the workgroup
     for (int t = tid; t < 3 * M; t += 256) { cha[t] = fv.ha[rb * 3 + t]; chb[t] = fv.hb[rb * 3 + t]; }
     for (int t = tid; t < M; t += 256) {
         ccs[t] = fv.hcs[rb + t];
-        lvec[t] = border ? Lsb[(long long)NTILES * 256 + t] : 0.0;
+        lvec[t] = (border && !first) ? Lsb[(long long)NTILES * 256 + t] : 0.0;
     }
     __syncthreads();
-    if (blk >= NT) return;
-    const double* prow = Pb + (long long)(16 * blk + li) * ldn;
-    const double px0 = prow[0], px1 = prow[1], px2 = prow[2];
-    auto tile = [&](int i, int k) { return Lsb + (long long)(k * MT - k * (k - 1) / 2 + (i - k)) * 256; };
+    SOLVER_STAMP(1);
+    // A wavefront without a row block only helps to stream the factor.  The two kinds of wavefront run separate copies of
+    // what follows (same barriers): with the products inside `if (has_blk)` blocks, the compiler sinks the last
+    // multiply-add of every entry of W into them and keeps its operands alive instead (2 KB of spills per lane).
+    auto run = [&](auto solving) {
+    constexpr bool SOLVE = decltype(solving)::value;
+    const double* prow = Pb + (long long)(16 * min(blk, NT - 1) + li) * ldn;
     // tile (blk, c) of W, transposed (accumulator layout of W^T): lane = state row li, measurement rows lk + 4 r
-    auto w_tile = [&](int c) {
-        v4d t;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int q = 16 * c + lk + 4 * r;
-            const double* pf = prow + max(ccs[q], 0);
-            double v = px0 * cha[3 * q];
-            v = fma(px1, cha[3 * q + 1], v);
-            v = fma(px2, cha[3 * q + 2], v);
-            v = fma(pf[0], chb[3 * q], v);
-            v = fma(pf[1], chb[3 * q + 1], v);
-            v = fma(pf[2], chb[3 * q + 2], v);
-            t[r] = v;
-        }
-        return t;
-    };
     v4d y[MT];
-    // Y^T_j = inv(L_jj) (W^T_j - sum_{k<j} L_jk Y^T_k): as forward_step of gain_solver_kernel
-    auto forward = [&](int j, v4d acc) {
-        double an[4];
-        auto fetch = [&](int k) {
-            const double* ta = tile(j, k);
+    if constexpr (SOLVE) {
+        const double px0 = prow[0], px1 = prow[1], px2 = prow[2];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) an[s] = ta[tsw(li, 4 * s + lk)];
-        };
-        fetch(0);
+        for (int c = 0; c < MT; ++c) {
 #pragma unroll
-        for (int k = 0; k < MT; ++k)
-            if (k < j) {
-                const double a0 = an[0], a1 = an[1], a2 = an[2], a3 = an[3];
-                fetch(k + 1);
-                v4d& c = acc;
-                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, y[k][0], c, 0, 0, 1);
-                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, y[k][1], c, 0, 0, 1);
-                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, y[k][2], c, 0, 0, 1);
-                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, y[k][3], c, 0, 0, 1);
+            for (int r = 0; r < 4; ++r) {
+                const int q = 16 * c + lk + 4 * r;
+                const double* pf = prow + max(ccs[q], 0);
+                double v = px0 * cha[3 * q];
+                v = fma(px1, cha[3 * q + 1], v);
+                v = fma(px2, cha[3 * q + 2], v);
+                v = fma(pf[0], chb[3 * q], v);
+                v = fma(pf[1], chb[3 * q + 1], v);
+                v = fma(pf[2], chb[3 * q + 2], v);
+                y[c][r] = v;
             }
-        v4d out = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) out = __builtin_amdgcn_mfma_f64_16x16x4f64(an[s], acc[s], out, 0, 0, 0);
-        return out;
+            // Four tiles at a time are finished here (one statement: every such statement costs a trip to memory, since
+            // no load moves across it).  Left alone, the compiler computes the tiles where the forward solve first uses
+            // them, one trip to memory per step of the solve.
+            if ((c & 3) == 3 || c == MT - 1) {
+                v4d& y0 = y[c & ~3];
+                v4d& y1 = y[(c & ~3) + 1 <= c ? (c & ~3) + 1 : c];
+                v4d& y2 = y[(c & ~3) + 2 <= c ? (c & ~3) + 2 : c];
+                v4d& y3 = y[c];
+                asm volatile("" : "+v"(y0[0]), "+v"(y0[1]), "+v"(y0[2]), "+v"(y0[3]), "+v"(y1[0]), "+v"(y1[1]), "+v"(y1[2]),
+                             "+v"(y1[3]));
+                asm volatile("" : "+v"(y2[0]), "+v"(y2[1]), "+v"(y2[2]), "+v"(y2[3]), "+v"(y3[0]), "+v"(y3[1]), "+v"(y3[2]),
+                             "+v"(y3[3]));
+            }
+        }
+    }
+    SOLVER_STAMP(2);
+    // place of tile (i, k), i >= k, in the image (column by column); the image is read through a buffer descriptor:
+    // the tile's offset is a scalar operand of the load, the thread's element its only address register
+    auto timg = [&](int i, int k) { return (k * MT - k * (k - 1) / 2 + (i - k)) * 256; };
+    const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(Lsb, 0, (int)(sSp * 8), 0x00020000);
+    typedef int v2i_t __attribute__((ext_vector_type(2)));
+    auto img_ld = [&](int tile_off) {
+        const v2i_t v = __builtin_amdgcn_raw_buffer_load_b64(img, tid * 8, tile_off * 8, 0);
+        return __hiloint2double(v.y, v.x);
     };
+    // this thread's element of every tile of a row / column, two rows ahead of the products: a row is requested two
+    // steps before it is copied to LDS, so its trip from L2 (or HBM: the images of a whole batch do not fit L2) has two
+    // steps of products to hide behind; the two register sets alternate with the parity of the row
+    double ld[2][MT];
+    // ---- Y^T_j = inv(L_jj) (W^T_j - sum_{k<j} L_jk Y^T_k), j ascending: as forward_step of gain_solver_kernel ----
+    // (one barrier per row: the buffer written in step j was last read in step j - 2, which every wavefront has left
+    // before it passed the barrier of step j - 1)
+    ld[0][0] = img_ld(timg(0, 0));
+    if (1 < MT) { ld[1][0] = img_ld(timg(1, 0)); ld[1][1] = img_ld(timg(1, 1)); }
+    __syncthreads();                                     // the tables are dead
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
-        y[j] = forward(j, w_tile(j));
-        __builtin_amdgcn_sched_barrier(0);               // one tile's entries of P in registers at a time
+        double* bj = buf[j & 1];
+#pragma unroll
+        for (int k = 0; k < MT; ++k)
+            if (k <= j) bj[k * 256 + tid] = ld[j & 1][k];
+        __syncthreads();
+        if (j + 2 < MT) {
+#pragma unroll
+            for (int k = 0; k < MT; ++k)
+                if (k <= j + 2) ld[j & 1][k] = img_ld(timg(j + 2, k));
+        }
+        if constexpr (SOLVE) {
+            v4d acc = y[j];
+            double an[4];
+            auto fetch = [&](int k) {
+                const double* ta = bj + k * 256;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) an[s] = ta[tsw(li, 4 * s + lk)];
+            };
+            fetch(0);
+#pragma unroll
+            for (int k = 0; k < MT; ++k)
+                if (k < j) {
+                    const double a0 = an[0], a1 = an[1], a2 = an[2], a3 = an[3];
+                    fetch(k + 1);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, y[k][0], acc, 0, 0, 1);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, y[k][1], acc, 0, 0, 1);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, y[k][2], acc, 0, 0, 1);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, y[k][3], acc, 0, 0, 1);
+                }
+            v4d out = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) out = __builtin_amdgcn_mfma_f64_16x16x4f64(an[s], acc[s], out, 0, 0, 0);
+            y[j] = out;
+        }
+        __builtin_amdgcn_sched_barrier(0);               // (one row of the pipeline at a time in the scheduler's view)
     }
+    SOLVER_STAMP(3);
+    // the last two columns of the factor are requested before the border step
+    ld[(MT - 1) & 1][MT - 1] = img_ld(timg(MT - 1, MT - 1));
+    if (MT > 1) { ld[(MT - 2) & 1][MT - 2] = img_ld(timg(MT - 2, MT - 2)); ld[(MT - 2) & 1][MT - 1] = img_ld(timg(MT - 1, MT - 2)); }
 
+    // ---- the altitude row as a border of the factored block (see gain_solver_kernel) ---------------------------------
     double k_alt = 0.0;
     if constexpr (BORDER) {
-        if (border) {                                    // as in gain_solver_kernel; l comes from the image
-            const double w_a = -prow[2], sigma = Pb[2 * ldn + 2] + rd[M];
-            double d = 0.0, ll = 0.0;
+        if (border) {
+            if (first) {
+                if constexpr (SOLVE) {
+                    if (blk == 0 && li == 2) {           // row 2 of Y_f: lane = column 2 of row block 0's Y^T tiles
 #pragma unroll
-            for (int j = 0; j < MT; ++j)
+                        for (int j = 0; j < MT; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double lq = lvec[16 * j + lk + 4 * r];
-                    d = fma(y[j][r], lq, d);
-                    ll = fma(lq, lq, ll);
+                            for (int r = 0; r < 4; ++r) {
+                                lvec[16 * j + lk + 4 * r] = -y[j][r];
+                                Lsb[(long long)NTILES * 256 + 16 * j + lk + 4 * r] = -y[j][r];
+                            }
+                    }
                 }
-            d += __shfl_xor(d, 16); d += __shfl_xor(d, 32);
-            ll += __shfl_xor(ll, 16); ll += __shfl_xor(ll, 32);
-            const double ilam = rsqrt_nr(sigma - ll);
-            k_alt = (w_a - d) * ilam * ilam;
+                __syncthreads();
+            }
+            if constexpr (SOLVE) {
+                const double w_a = -prow[2], sigma = Pb[2 * ldn + 2] + rd[M];
+                double d = 0.0, ll = 0.0;
 #pragma unroll
-            for (int j = 0; j < MT; ++j)
+                for (int j = 0; j < MT; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) y[j][r] = fma(-k_alt, lvec[16 * j + lk + 4 * r], y[j][r]);
-            if (lk == 0) {                               // the altitude column of K
-                K[(long long)b * sNM + (long long)(16 * blk + li) * ldm + M] = k_alt;
-                if (KR) KR[(long long)b * sNM + (long long)(16 * blk + li) * ldm + M] = k_alt * rd[M];
+                    for (int r = 0; r < 4; ++r) {
+                        const double lq = lvec[16 * j + lk + 4 * r];
+                        d = fma(y[j][r], lq, d);         // this lane group's share of (Y_f l)_a
+                        ll = fma(lq, lq, ll);
+                    }
+                d += __shfl_xor(d, 16); d += __shfl_xor(d, 32);
+                ll += __shfl_xor(ll, 16); ll += __shfl_xor(ll, 32);
+                const double lam2 = sigma - ll;
+                if (first && !(lam2 > 0.0) && tid == 0) atomicOr(fv.status + b, 2);   // S was not positive definite
+                const double ilam = rsqrt_nr(lam2);
+                k_alt = (w_a - d) * ilam * ilam;
+                asm volatile("" ::: "memory");           // l is read again below, not kept in 2 M / 16 registers meanwhile
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[j][r] = fma(-k_alt, lvec[16 * j + lk + 4 * r], y[j][r]);
+                if (lk == 0) {                           // the altitude column of K
+                    K[(long long)b * sNM + (long long)(16 * blk + li) * ldm + M] = k_alt;
+                    if (KR) KR[(long long)b * sNM + (long long)(16 * blk + li) * ldm + M] = k_alt * rd[M];
+                }
             }
         }
     }
-    // K^T_j = inv(L_jj)^T (Y^T_j - sum_{k>j} L_kj^T K^T_k),  j = MT-1 .. 0
-    double* stg = stgs[wave];
-    double* Kb = K + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li;
-    double* KRb = KR ? KR + (long long)b * sNM + (long long)(16 * blk + lk) * ldm + li : nullptr;
-    double mag = fabs(k_alt);
+    // ---- K^T_j = inv(L_jj)^T (Y^T_j - sum_{k>j} L_kj^T K^T_k),  j = MT-1 .. 0 ------------------------------------------
+    SOLVER_STAMP(4);
+    double* stg = stgs + wave * 256;
+    double* Kb = K + (long long)b * sNM + (long long)(16 * min(blk, NT - 1) + lk) * ldm + li;
+    double* KRb = KR ? KR + (long long)b * sNM + (long long)(16 * min(blk, NT - 1) + lk) * ldm + li : nullptr;
+    double mag = fabs(k_alt);                            // a pivot that was not positive has made K NaN or infinite
+    __syncthreads();                                     // the last rows of the forward solve are done with
 #pragma unroll
     for (int j = MT - 1; j >= 0; --j) {
-        v4d acc = y[j];
+        double* bj = buf[j & 1];
 #pragma unroll
-        for (int k = j + 1; k < MT; ++k) acc = tile_mma_regB<true, true>(tile(k, j), y[k], acc, li, lk);
-        y[j] = tile_mma_regB<true, false>(tile(j, j), acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
+        for (int k = 0; k < MT; ++k)
+            if (k >= j) bj[k * 256 + tid] = ld[j & 1][k];       // tile (k, j) in place k
+        __syncthreads();
+        if (j > 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) stg[tsw(li, lk + 4 * r)] = y[j][r];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double v = stg[tsw(lk + 4 * r, li)];
-            mag += fabs(v);
-            Kb[(long long)(4 * r) * ldm + 16 * j] = v;
-            if (KRb) KRb[(long long)(4 * r) * ldm + 16 * j] = v * rd[16 * j + li];
+            for (int k = 0; k < MT; ++k)
+                if (k >= j - 2) ld[j & 1][k] = img_ld(timg(k, j - 2));
         }
-        __builtin_amdgcn_sched_barrier(0);               // (the tiles of one row of products in registers at a time)
+        if constexpr (SOLVE) {
+            v4d acc = y[j];
+#pragma unroll
+            for (int k = j + 1; k < MT; ++k) acc = tile_mma_regB<true, true>(bj + k * 256, y[k], acc, li, lk);
+            y[j] = tile_mma_regB<true, false>(bj + j * 256, acc, (v4d){0.0, 0.0, 0.0, 0.0}, li, lk);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stg[tsw(li, lk + 4 * r)] = y[j][r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = stg[tsw(lk + 4 * r, li)];
+                mag += fabs(v);
+                Kb[(long long)(4 * r) * ldm + 16 * j] = v;
+                if (KRb) KRb[(long long)(4 * r) * ldm + 16 * j] = v * rd[16 * j + li];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
-    if (!(mag < 1.0e300)) atomicOr(fv.status + b, 2);    // S was not positive definite
+    if (SOLVE && !(mag < 1.0e300)) atomicOr(fv.status + b, 2);    // S was not positive definite
+    SOLVER_STAMP(5);
+    };
+    if (has_blk) run(std::true_type{});
+    else run(std::false_type{});
 }
+constexpr int gain_rows_lds_tiles(int MT) { return 2 * MT + 5; }
 
 // Diagonal block of the blocked Cholesky of a large S: factor the 16 MT x 16 MT block at (j0, j0) (lower part
 // valid) into L and write inv(L) of the block into Li, one workgroup per matrix of the batch.  The inverse is

@@ -266,7 +266,7 @@ int max_m(const slamk_handle* h)
 }
 
 constexpr int SOLVER_MAX_MT = 15, SOLVER_MAX_NT = 8;
-// 9 to 12 row blocks of 16 states: the solver's wide form (panels of 12 tiles; row blocks 8.. of K by
+// 9 to 12 row blocks of 16 states: the solver's wide form (panels of 12 tiles, factorisation only; K by
 // gain_rows_kernel from the image of the factor); it keeps the factor in the ring form, whose LDS holds up to 15 tile
 // columns with the wider panels
 // (more than 128 states are at least 40 features, i.e. at least 161 measurement rows: 10 tile columns)
@@ -743,9 +743,21 @@ int launch_gain_solver(slamk_handle* h, const Range& rg, int nl, double* Lout, d
         const long long sM = (long long)h->ldm * h->ldm, sNM = (long long)h->ldn * h->ldm;
         hipLaunchKernelGGL((gain_solver_kernel<MT, BORDER, SPILL, WIDE>), dim3(rg.B), dim3(512), lds, st, rg.fv, rg.K, KRout,
                            Lout, sM, sNM, nl / 16, rg.Lsp, (long long)SOLVER_SPILL_IMAGE);
-        if constexpr (WIDE)
-            hipLaunchKernelGGL((gain_rows_kernel<MT, BORDER>), dim3(rg.B), dim3(256), 0, st, rg.fv, rg.K, KRout, sNM, nl / 16,
-                               rg.Lsp, (long long)SOLVER_SPILL_IMAGE);
+        if constexpr (WIDE) {                            // the two solves: row blocks 0..3, then the rest
+            const size_t lr = (size_t)gain_rows_lds_tiles(MT) * 256 * sizeof(double);
+            int rc_ = ensure_dynamic_lds(h, reinterpret_cast<const void*>(gain_rows_kernel<MT, BORDER>), lr);
+            if (rc_) return rc_;
+            const int NT = nl / 16;
+            auto rows = [&](int blk0, int G) {   // G workgroups per filter, the eight XCDs taking filters in turn
+                hipLaunchKernelGGL((gain_rows_kernel<MT, BORDER>), dim3(8 * ((rg.B + 7) / 8) * G), dim3(256), lr, st, rg.fv, rg.K,
+                                   KRout, sNM, NT, blk0, G, rg.Lsp, (long long)SOLVER_SPILL_IMAGE);
+            };
+            if constexpr (BORDER) {      // the border's l comes from row block 0: its workgroup first, the others behind it
+                rows(0, 1);
+                rows(4, (NT - 4 + 3) / 4);
+            } else                       // one launch: 9 row blocks are three workgroups of three
+                rows(0, (NT + 3) / 4);
+        }
         HIPCHK(h, hipGetLastError());
         return 0;
     }
