@@ -743,11 +743,21 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
 #pragma unroll
                 for (int r = 0; r < 4; ++r) y[c < MT ? c : 0][r] = pan[blk * 256 + tsw(li, lk + 4 * r)];
             };
+            // WIDE: every tile of W waits in its place in K (row-major, the row block's rows) for gain_rows_kernel: the
+            // seven building wavefronts copy panel c out when it is complete
+            auto park_all = [&](int c) {
+                const double* pan = pan_of(c);
+                for (int t = wave - 1; t < NT; t += 7) {
+                    double* kx = K + (long long)b * sNM + (long long)(16 * t) * ldm + 16 * c;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) kx[(long long)li * ldm + lk + 4 * r] = pan[t * 256 + tsw(li, lk + 4 * r)];
+                }
+            };
             write_panel(0);
             if (1 < MT) load_panel(1);
             __syncthreads();                             // panel 0 is in LDS
             for (int i = wk6; i < MT; i += 7) form_tile(i, 0);
-            if constexpr (!WIDE) { if (has_blk) take_y(0); }
+            if constexpr (!WIDE) { if (has_blk) take_y(0); } else park_all(0);
             if (1 < MT) {
                 write_panel(1);
                 if (2 < MT) load_panel(2);
@@ -756,7 +766,7 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
             SOLVER_STAMP(1);
             if (1 < MT) {
                 for (int i = 1 + wk6; i < MT; i += 7) form_tile(i, 1);
-                if constexpr (!WIDE) { if (has_blk) take_y(1); }
+                if constexpr (!WIDE) { if (has_blk) take_y(1); } else park_all(1);
             }
             if (2 < MT) {
                 write_panel(2);
@@ -779,7 +789,7 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
                         form_tile(i, j + 2);
                         update_tile(i, j + 2, 0, j, thr_at(j + 2));
                     }
-                    if constexpr (!WIDE) { if (has_blk) take_y(j + 2); }
+                    if constexpr (!WIDE) { if (has_blk) take_y(j + 2); } else park_all(j + 2);
                 }
                 if constexpr (!WIDE) { if (has_blk) y[j] = forward_step(j, y[j], thr_at(j + 2)); }
                 SOLVER_STAMP(2 + j);
@@ -880,8 +890,8 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
 // K for filters of 9 to 12 row blocks of 16 states, launched behind gain_solver_kernel<MT, BORDER, true, true>, which
 // only factors S for them and leaves every tile of the factor (L_ij below the diagonal, inv(L_jj) on it) in the image
 // Lsp.  A workgroup of four wavefronts takes up to four row blocks of W / K from blk0 on, one per wavefront:
-//   - each wavefront forms its tiles of W = P H^T (src/slam/main.cpp:545) itself: the same six products per entry in
-//     the same order as the panels of the solver;
+//   - each wavefront takes its tiles of W = P H^T (src/slam/main.cpp:545) from its row block's rows of K, where the
+//     solver kernel has left a copy of every panel it built (and where the gain replaces them at the end);
 //   - the forward solve walks the rows of the factor, the backward solve its columns; the four wavefronts need the same
 //     tiles at the same time, so the workgroup streams them through LDS: all 256 threads copy row j + 1 (column j - 1)
 //     of tiles from the image (L2) into one buffer while the products of row j run from the other: one barrier and one
@@ -900,10 +910,6 @@ __global__ void __launch_bounds__(256, 2) gain_rows_kernel(FilterView fv, double
     double* buf[2] = {lds, lds + MT * 256};              // a row / column of tiles of the factor each
     double* stgs = lds + 2 * MT * 256;                   // one staging tile per wavefront
     double* lvec = stgs + 4 * 256;                       // [M]
-    // before the solves the buffers hold the compact rows of H: ha, hb [M][3], cs [M] (6.5 M doubles of 512 MT)
-    double* cha = lds;
-    double* chb = cha + 3 * M;
-    int* ccs = reinterpret_cast<int*>(chb + 3 * M);
     // The G workgroups of a filter stream the same image: they sit next to each other on one XCD (consecutive workgroup
     // numbers go round the eight XCDs), so the image comes from HBM once and from that XCD's L2 after that.
     const int wg = (int)blockIdx.x >> 3, by = wg % G;
@@ -924,12 +930,7 @@ __global__ void __launch_bounds__(256, 2) gain_rows_kernel(FilterView fv, double
     double* Lsb = Lsp + (long long)b * sSp;
     bool border = false;
     if constexpr (BORDER) border = (fv.m[b] - 1 == M);   // uniform over the workgroup
-    for (int t = tid; t < 3 * M; t += 256) { cha[t] = fv.ha[rb * 3 + t]; chb[t] = fv.hb[rb * 3 + t]; }
-    for (int t = tid; t < M; t += 256) {
-        ccs[t] = fv.hcs[rb + t];
-        lvec[t] = (border && !first) ? Lsb[(long long)NTILES * 256 + t] : 0.0;
-    }
-    __syncthreads();
+    for (int t = tid; t < M; t += 256) lvec[t] = (border && !first) ? Lsb[(long long)NTILES * 256 + t] : 0.0;
     SOLVER_STAMP(1);
     // A wavefront without a row block only helps to stream the factor.  The two kinds of wavefront run separate copies of
     // what follows (same barriers): with the products inside `if (has_blk)` blocks, the compiler sinks the last
@@ -939,36 +940,12 @@ __global__ void __launch_bounds__(256, 2) gain_rows_kernel(FilterView fv, double
     const double* prow = Pb + (long long)(16 * min(blk, NT - 1) + li) * ldn;
     // tile (blk, c) of W, transposed (accumulator layout of W^T): lane = state row li, measurement rows lk + 4 r
     v4d y[MT];
-    if constexpr (SOLVE) {
-        const double px0 = prow[0], px1 = prow[1], px2 = prow[2];
+    if constexpr (SOLVE) {                               // all requested at once: one trip to memory
+        const double* wrow = K + (long long)b * sNM + (long long)(16 * blk + li) * ldm + lk;
 #pragma unroll
-        for (int c = 0; c < MT; ++c) {
+        for (int c = 0; c < MT; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = 16 * c + lk + 4 * r;
-                const double* pf = prow + max(ccs[q], 0);
-                double v = px0 * cha[3 * q];
-                v = fma(px1, cha[3 * q + 1], v);
-                v = fma(px2, cha[3 * q + 2], v);
-                v = fma(pf[0], chb[3 * q], v);
-                v = fma(pf[1], chb[3 * q + 1], v);
-                v = fma(pf[2], chb[3 * q + 2], v);
-                y[c][r] = v;
-            }
-            // Four tiles at a time are finished here (one statement: every such statement costs a trip to memory, since
-            // no load moves across it).  Left alone, the compiler computes the tiles where the forward solve first uses
-            // them, one trip to memory per step of the solve.
-            if ((c & 3) == 3 || c == MT - 1) {
-                v4d& y0 = y[c & ~3];
-                v4d& y1 = y[(c & ~3) + 1 <= c ? (c & ~3) + 1 : c];
-                v4d& y2 = y[(c & ~3) + 2 <= c ? (c & ~3) + 2 : c];
-                v4d& y3 = y[c];
-                asm volatile("" : "+v"(y0[0]), "+v"(y0[1]), "+v"(y0[2]), "+v"(y0[3]), "+v"(y1[0]), "+v"(y1[1]), "+v"(y1[2]),
-                             "+v"(y1[3]));
-                asm volatile("" : "+v"(y2[0]), "+v"(y2[1]), "+v"(y2[2]), "+v"(y2[3]), "+v"(y3[0]), "+v"(y3[1]), "+v"(y3[2]),
-                             "+v"(y3[3]));
-            }
-        }
+            for (int r = 0; r < 4; ++r) y[c][r] = wrow[16 * c + 4 * r];
     }
     SOLVER_STAMP(2);
     // place of tile (i, k), i >= k, in the image (column by column); the image is read through a buffer descriptor:
@@ -989,7 +966,7 @@ __global__ void __launch_bounds__(256, 2) gain_rows_kernel(FilterView fv, double
     // before it passed the barrier of step j - 1)
     ld[0][0] = img_ld(timg(0, 0));
     if (1 < MT) { ld[1][0] = img_ld(timg(1, 0)); ld[1][1] = img_ld(timg(1, 1)); }
-    __syncthreads();                                     // the tables are dead
+    __syncthreads();                                     // (l is in LDS)
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         double* bj = buf[j & 1];
