@@ -903,7 +903,8 @@ __global__ void __launch_bounds__(512, (MT <= 3 ? 4 : 2)) gain_solver_kernel(Fil
 // 256 registers per wavefront hold a whole row of tiles of Y^T; (2 MT + 5) tiles of LDS: two workgroups per CU.
 template <int MT, bool BORDER>
 __global__ void __launch_bounds__(256, 2) gain_rows_kernel(FilterView fv, double* __restrict__ K, double* __restrict__ KR, long long sNM,
-                                                           int NT, int blk0, int G, double* __restrict__ Lsp, long long sSp)
+                                                           int NT, int blk0, int G, double* __restrict__ Lsp, long long sSp,
+                                                           double* __restrict__ Ldbg = nullptr, long long sM = 0)
 {
     constexpr int M = 16 * MT, NTILES = MT * (MT + 1) / 2;
     extern __shared__ double lds[];                     // gain_rows_lds_tiles(MT) tiles
@@ -1045,6 +1046,11 @@ __global__ void __launch_bounds__(256, 2) gain_rows_kernel(FilterView fv, double
                 if (first && !(lam2 > 0.0) && tid == 0) atomicOr(fv.status + b, 2);   // S was not positive definite
                 const double ilam = rsqrt_nr(lam2);
                 k_alt = (w_a - d) * ilam * ilam;
+                if (Ldbg && first && blk == 0) {         // the factor's last row, for introspection
+                    double* Lb = Ldbg + (long long)b * sM;
+                    for (int q = lane; q < M; q += 64) Lb[(long long)M * ldm + q] = lvec[q];
+                    if (lane == 0) Lb[(long long)M * ldm + M] = lam2 * ilam;
+                }
                 asm volatile("" ::: "memory");           // l is read again below, not kept in 2 M / 16 registers meanwhile
 #pragma unroll
                 for (int j = 0; j < MT; ++j)

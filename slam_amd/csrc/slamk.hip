@@ -750,7 +750,7 @@ int launch_gain_solver(slamk_handle* h, const Range& rg, int nl, double* Lout, d
             const int NT = nl / 16;
             auto rows = [&](int blk0, int G) {   // G workgroups per filter, the eight XCDs taking filters in turn
                 hipLaunchKernelGGL((gain_rows_kernel<MT, BORDER>), dim3(8 * ((rg.B + 7) / 8) * G), dim3(256), lr, st, rg.fv, rg.K,
-                                   KRout, sNM, NT, blk0, G, rg.Lsp, (long long)SOLVER_SPILL_IMAGE);
+                                   KRout, sNM, NT, blk0, G, rg.Lsp, (long long)SOLVER_SPILL_IMAGE, Lout, sM);
             };
             if constexpr (BORDER) {      // the border's l comes from row block 0: its workgroup first, the others behind it
                 rows(0, 1);

@@ -219,13 +219,17 @@ def test_random_configurations_against_oracle(seed):
     print("worst rel err over the sweep %.2e" % worst)
 
 
-def test_per_function_parity():
-    """F, H, innovation, Cholesky factor and gain of one step against the oracle's functions."""
-    st = synth.gen_stream(seed=4, nf=14, steps=7, churn=False)
+@pytest.mark.parametrize("nf,ref_fraction", [(14, None), (40, 0.0), (43, 0.5)])
+def test_per_function_parity(nf, ref_fraction):
+    """F, H, innovation, Cholesky factor and gain of one step against the oracle's functions; also where the factor comes
+    from the solver's wide form and its image (129 and 138 states), with the altitude row as border (m = 161) and inside
+    the tiles."""
+    kw = {} if ref_fraction is None else {"ref_fraction": ref_fraction}
+    st = synth.gen_stream(seed=4, nf=nf, steps=7, churn=False, **kw)
     inp = helpers.stream_inputs(st, 7)
     f = orc.Filter()
     f.X = st.init_pos
-    fb = ekf.FilterBatch(max_features=14, batch=1)
+    fb = ekf.FilterBatch(max_features=nf, batch=1)
     fb.set_debug(True)
     fb.set_state(0, X=st.init_pos)
     u, quat, ang, acc, dt, matches = inp[0]
