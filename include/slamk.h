@@ -305,6 +305,9 @@ int slamk_mfma_f64_probe(int iters, double* tflops);
  * I - K H), 3 GEMMs of the gain on the large-map path (Y, K), 4 GEMMs of the covariance update,
  * 5 GEMMs inside the Cholesky factorisation / triangular inverse, 6 diagonal-block factorisation
  * kernel, 7 fused per-filter gain solver of the small-filter path (ncat >= 8).
+ * slamk_profile_enable: on = 0 no stage is timed, 1 all of them, any other value a set of categories with bit
+ * (c + 1) for category c (every timed scope costs two event records on the stream, a few microseconds: a caller who
+ * wants one kernel's time beside an undisturbed throughput figure selects that stage only).
  * slamk_profile_read synchronises, returns the accumulated milliseconds
  * and scope counts since the previous read, and resets them. */
 int slamk_profile_enable(slamk_handle* h, int on);

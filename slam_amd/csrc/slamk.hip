@@ -110,7 +110,7 @@ struct slamk_handle {
     struct GraphEntry { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;
     // optional per-stage timing with HIP events on the launch stream (slamk_profile_*)
-    bool prof_on = false;
+    unsigned prof_mask = 0;                 // bit c: stage category c is timed
     struct ProfRec { int cat; hipEvent_t a, b; };
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
@@ -206,7 +206,7 @@ struct ProfScope {
     slamk_handle* h; hipStream_t st; hipEvent_t b = nullptr;
     ProfScope(slamk_handle* h_, int cat, hipStream_t st_) : h(h_), st(st_)
     {
-        if (!h->prof_on) return;
+        if (!((h->prof_mask >> cat) & 1u)) return;
         hipEvent_t ev[2];
         for (auto& e : ev) {
             if (!h->prof_pool.empty()) { e = h->prof_pool.back(); h->prof_pool.pop_back(); }
@@ -1661,7 +1661,7 @@ int slamk_step_dev(slamk_handle* h, const double* qbw_dev, const double* w_dev, 
     // others get their frame begin here, in launches of their own, and the step itself runs none.
     if (h->nbegun > 0 && h->nbegun < h->B) { int rc_ = begin_remaining(h, st); if (rc_) return rc_; }
     const bool frame_begin = h->nbegun < h->B;
-    if (h->graph_mode && !h->prof_on && st != nullptr) {
+    if (h->graph_mode && !h->prof_mask && st != nullptr) {
         // replay (or first capture) the launch sequence as one hipGraph: one submission per iteration
         slamk_handle::GraphKey key;
         memset(&key, 0, sizeof key);
@@ -2458,7 +2458,7 @@ int slamk_mfma_f64_probe(int iters, double* tflops)
 int slamk_profile_enable(slamk_handle* h, int on)
 {
     if (!h) return SLAMK_EINVAL;
-    h->prof_on = on != 0;
+    h->prof_mask = on == 0 ? 0u : (on == 1 ? ~0u : (unsigned)on >> 1);
     return SLAMK_OK;
 }
 

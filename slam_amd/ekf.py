@@ -182,8 +182,12 @@ class FilterBatch:
     PROFILE_STAGES = ("feature_kernels", "struct_predict", "struct_gain", "gemm_gain", "gemm_cov_update",
                       "gemm_cholesky", "potf2_inv", "gain_solver")
 
-    def profile_enable(self, on=True):
-        self._chk(self.L.slamk_profile_enable(self.h, int(bool(on))))
+    def profile_enable(self, on=True, stages=None):
+        """Stage timers on or off; `stages` (names from PROFILE_STAGES) times only those."""
+        v = int(bool(on))
+        if on and stages is not None:
+            v = sum(1 << (self.PROFILE_STAGES.index(k) + 1) for k in stages)
+        self._chk(self.L.slamk_profile_enable(self.h, v))
 
     def profile_read(self):
         """{stage: (milliseconds, scopes)} accumulated since the last read (HIP events on the launch stream)."""

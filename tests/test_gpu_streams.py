@@ -260,3 +260,35 @@ def test_batch_frames_on_a_stream_match_per_filter_frames():
     assert ei.value.code == -5
     for fb in fbs:
         fb.close()
+
+
+def test_stage_timers_can_be_limited_to_chosen_stages():
+    """slamk_profile_enable with a set of categories: only those stages record events (and report scopes); 1 times all
+    of them, 0 none."""
+    st = synth.gen_stream(seed=3, nf=12, steps=4, churn=False, image_every=1)
+    inp = helpers.stream_inputs(st, 3)
+    fb = ekf.FilterBatch(max_features=12, batch=2)
+    for b in range(2):
+        fb.set_state(b, X=st.init_pos)
+    fb.frame(-1, inp[0][5], inp[0][1])
+
+    def step(k):
+        u, quat, ang, acc, dt, matches = inp[k]
+        fb.frame(-1, matches, quat)
+        fb.predict(np.tile(quat, 2), np.tile(ang, 2), np.tile(acc, 2), np.full(2, dt))
+        fb.update(np.tile(quat, 2))
+
+    fb.profile_enable(True, stages=("gain_solver",))
+    fb.profile_read()
+    step(1)
+    p = fb.profile_read()
+    assert p["gain_solver"][1] == 1 and p["gain_solver"][0] > 0
+    assert all(v[1] == 0 for k, v in p.items() if k != "gain_solver")
+    fb.profile_enable(True)
+    step(2)
+    p = fb.profile_read()
+    assert p["gain_solver"][1] == 1 and p["struct_predict"][1] >= 1 and p["gemm_cov_update"][1] >= 1
+    fb.profile_enable(False)
+    step(3)
+    assert all(v[1] == 0 for v in fb.profile_read().values())
+    fb.close()
