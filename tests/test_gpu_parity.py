@@ -388,7 +388,8 @@ def test_shared_frame_with_feature_churn_is_applied_to_the_whole_batch():
         fb.close()
 
 
-@pytest.mark.parametrize("groups,form,nf", [(1, 0, 12), (3, 0, 12), (1, 2, 12), (3, 2, 12), (1, 2, 33), (1, 2, 50), (1, 2, 1)])
+@pytest.mark.parametrize("groups,form,nf", [(1, 0, 12), (3, 0, 12), (1, 2, 12), (3, 2, 12), (1, 2, 33), (1, 2, 50), (1, 2, 1),
+                                            (3, 0, 44), (2, 0, 36)])
 def test_step_call_matches_the_three_calls(groups, form, nf):
     import torch
     """slamk_step_dev (whole iteration, batch cut into ranges on streams of their own) == frame_begin + predict + update.
