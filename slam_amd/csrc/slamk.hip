@@ -639,10 +639,17 @@ int cholesky_inverse(slamk_handle* h, double* Sp, double* Lp, double* Lip, int l
         const int ncu = prop.multiProcessorCount;
         std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
         static const int spare = [] { const char* e = getenv("SLAMK_CHOL_SPARE_CUS"); return e ? atoi(e) : 32; }();
-        for (int c = std::min(spare, ncu - 1); c < ncu; ++c) mask[c / 32] |= 1u << (c % 32);
-        HIPCHK(h, hipExtStreamCreateWithCUMask(&h->chol_side, (uint32_t)mask.size(), mask.data()));
-        HIPCHK(h, hipEventCreateWithFlags(&h->chol_panel_done, hipEventDisableTiming));
-        HIPCHK(h, hipEventCreateWithFlags(&h->chol_rest_done, hipEventDisableTiming));
+        for (int c = std::max(0, std::min(spare, ncu - 1)); c < ncu; ++c) mask[c / 32] |= 1u << (c % 32);
+        // (a device or partition mode that refuses the mask: the single update on the launch stream, for good)
+        if (spare < 0 || hipExtStreamCreateWithCUMask(&h->chol_side, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            h->chol_side = nullptr;
+            h->chol_lookahead = false;
+            ahead = false;
+        } else {
+            HIPCHK(h, hipEventCreateWithFlags(&h->chol_panel_done, hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&h->chol_rest_done, hipEventDisableTiming));
+        }
     }
     bool rest_pending = false;                           // the second stream holds an update the launch stream has not joined
     for (int J0 = 0; J0 < ml; J0 += OB) {
